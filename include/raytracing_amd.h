@@ -1,0 +1,172 @@
+/*
+ * raytracing_amd.h — C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * The upstream renderer (m-J-K-b/raytracing) is pure Python and has no FFI of its own; the seam
+ * this library sits behind is its Python object API.  Every entry point below therefore names the
+ * upstream function whose work it takes over (file:line under the upstream tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only, no C++ or torch types.
+ *   - Every function returns an rt_status (0 = ok).  Nothing throws across the boundary; the text
+ *     of the last failure on a context is available from rt_last_error().
+ *   - The caller owns every array it passes in; the library copies what it needs during the call.
+ *     Device memory allocated by the library lives until rt_destroy().
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP device memory of the
+ *     context's GPU.  `stream` arguments are a hipStream_t passed as void* (NULL = default stream).
+ *   - Image layout follows the upstream accumulation array RenderResult.arr
+ *     (src/raytracing/render_result.py:14): shape (W, H, 3), x-major, y up, un-normalised SUM of
+ *     per-sample radiance; element (x, y, c) sits at ((x * H) + y) * 3 + c.
+ *   - One render call in flight per context; rt_request_stop / rt_get_stats / rt_last_error may be
+ *     called from other threads while it runs.
+ */
+#ifndef RAYTRACING_AMD_H
+#define RAYTRACING_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = 1,   /* NULL pointer, negative count, inconsistent table sizes, ... */
+    RT_ERR_NO_SCENE = 2,      /* render / intersect before rt_set_scene */
+    RT_ERR_HIP = 3,           /* a HIP runtime call failed; see rt_last_error */
+    RT_ERR_NO_DEVICE = 4,     /* no usable GPU / bad device ordinal */
+    RT_ERR_STOPPED = 5,       /* rt_request_stop was raised before or during the call */
+    RT_ERR_UNSUPPORTED = 6
+} rt_status;
+
+enum { RT_OBJ_SPHERE = 0, RT_OBJ_MESH = 1 };
+
+/*
+ * Flat description of one scene: what the host packer extracts from the upstream objects
+ *   scene.objects[i].material.{color,emission_strength,smoothness,transmittance,ior}  (src/core/material.py:8-21)
+ *   Sphere.origin / Sphere.radius                                                      (src/mesh/sphere.py:9-11)
+ *   Mesh.transformed_vertices / Mesh.triangles / Mesh.bounding_box                     (src/mesh/mesh.py:25-59)
+ *   scene.camera.{pos,right,up,forward,d,dof_strength,dof_dist}                        (src/raytracing/camera.py:9-37)
+ *   the scene module's sky_map + its scale factor                                      (scenes/room.py:15-22)
+ * All geometry is double precision exactly as the Python objects hold it; the library derives its
+ * own float32 working copies.  Object order is scene.objects order and defines hit tie-breaks
+ * (src/raytracing/scene.py:23-27: stable sort by depth over objects, then per-object hit order).
+ */
+typedef struct rt_scene_desc {
+    uint32_t struct_size;          /* = sizeof(rt_scene_desc), checked */
+    int32_t n_objects;
+    const int32_t *obj_kind;       /* [n_objects] RT_OBJ_SPHERE | RT_OBJ_MESH */
+    const int32_t *obj_index;      /* [n_objects] index into spheres[] or meshes */
+    const double *materials;       /* [n_objects][7] r,g,b, emission_strength, smoothness, transmittance, ior */
+
+    int32_t n_spheres;
+    const double *spheres;         /* [n_spheres][4] cx,cy,cz,radius */
+    const int32_t *sphere_obj;     /* [n_spheres] owning object index */
+
+    int32_t n_meshes;
+    const double *mesh_aabb;       /* [n_meshes][6] min xyz, max xyz  (Mesh.bounding_box) */
+    const int32_t *mesh_obj;       /* [n_meshes] owning object index */
+    const int32_t *mesh_tri_begin; /* [n_meshes+1] first triangle of each mesh in tri_verts */
+    int32_t n_tris;
+    const double *tri_verts;       /* [n_tris][9] a,b,c (transformed vertices of each face, face order) */
+
+    double cam_pos[3], cam_right[3], cam_up[3], cam_forward[3];
+    double cam_d, cam_dof_strength, cam_dof_dist;
+
+    int32_t sky_w, sky_h;          /* 0,0 => black environment (Scene.get_environment default, scene.py:35-36) */
+    const uint8_t *sky_rgb;        /* [sky_h][sky_w][3] row-major, as decoded from the image file */
+    double sky_scale;              /* radiance = texel/255 * sky_scale */
+
+    /* Optional host-built flat BVH over ALL triangles (no upstream counterpart: it replaces the
+     * linear loops of Mesh.intersect, src/mesh/mesh.py:94-107).  n_bvh_nodes == 0 selects the
+     * brute-force kernels.  Layout: see rt_bvh_node. */
+    int32_t n_bvh_nodes;
+    const void *bvh_nodes;         /* [n_bvh_nodes] rt_bvh_node */
+    const int32_t *bvh_tri_index;  /* [n_tris] triangle ids in leaf order */
+} rt_scene_desc;
+
+/* Depth-first ("threaded") BVH node: if the ray misses the box, or after a leaf has been
+ * processed, traversal continues at `skip`; otherwise at the next node in memory. */
+typedef struct rt_bvh_node {
+    float lo[3];
+    int32_t skip;                  /* index of the node to continue with on a miss; -1 = done */
+    float hi[3];
+    int32_t tri_begin_count;       /* leaf: (first << 4) | count (count 1..15); inner: -1 */
+} rt_bvh_node;
+
+typedef struct rt_render_params {
+    uint32_t struct_size;
+    int32_t width, height;         /* RenderSettings.WIDTH/HEIGHT (render_settings.py:15-16) */
+    int32_t x0, x1, y0, y1;        /* pixel rectangle, as the `area` tuple of render_area (renderer.py:90-91) */
+    int32_t sample_begin;          /* global index of the first sample (pass) of this call */
+    int32_t sample_count;          /* number of samples (passes) to add per pixel */
+    int32_t max_bounces;           /* RenderSettings.MAX_BOUNCES (render_settings.py:19) */
+    uint64_t seed;                 /* mixed into the Philox key with (pixel, sample) */
+} rt_render_params;
+
+typedef struct rt_stats {
+    uint64_t rays;                 /* closest-hit queries = Scene.intersect calls (scene.py:23) */
+    uint64_t paths;                /* top-level raytrace calls (renderer.py:105) */
+    uint64_t sphere_tests, tri_tests, aabb_tests, bvh_node_tests; /* float32 filter tests executed */
+    uint64_t exact_rays;           /* rays re-evaluated by the double-precision exact scan */
+    uint64_t sky_lookups, shaded_hits;
+    double kernel_ms;              /* device time of the dominant kernel, summed over launches */
+    uint64_t launches;
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Library / lifetime ----------------------------------------------------------------------- */
+int rt_abi_version(void);
+/* Create a context bound to HIP device `device_id`.  Takes over nothing upstream (the upstream
+ * renderer has no device); pairs with Renderer.__init__ (renderer.py:15-19). */
+int rt_create(int device_id, rt_ctx **out);
+int rt_destroy(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: last error of a failed rt_create */
+
+/* Scene upload: what Renderer.init_render binds (renderer.py:81-88, `self.scene = ...SCENE`). */
+int rt_set_scene(rt_ctx *ctx, const rt_scene_desc *scene);
+
+/* Closest-hit query for n arbitrary rays: Scene.intersect(ray)[0] (scene.py:23-27) with
+ * Sphere.intersect (sphere.py:13-41), Mesh.intersect / intersect_aabb / intersect_tri
+ * (mesh.py:61-143).  Host arrays.  obj = index into scene.objects or -1; prim = face index inside
+ * the mesh, or 0/1 = near/far root for a sphere; t, normal (unit, as the object returns it, not
+ * flipped), pos are doubles.  `origin_prim` (may be NULL) marks rays that start ON a primitive as
+ * bounce rays do: value = global primitive id as returned in `gprim`, -1 = none. */
+int rt_intersect_batch(rt_ctx *ctx, int64_t n, const double *org, const double *dir,
+                       const int32_t *origin_prim, int32_t *obj, int32_t *prim, int32_t *gprim,
+                       double *t, double *normal, double *pos);
+
+/* Accumulation buffer: RenderResult.arr (render_result.py:14,24-27).  The context owns one
+ * float32 (W,H,3) device buffer, (re)allocated by rt_accum_resize and zeroed. */
+int rt_accum_resize(rt_ctx *ctx, int32_t width, int32_t height);
+int rt_accum_clear(rt_ctx *ctx);
+void *rt_accum_device_ptr(rt_ctx *ctx);                 /* for zero-copy tensor hand-off; NULL if none */
+int rt_accum_read(rt_ctx *ctx, float *host_w_h_3);      /* blocking copy of the whole buffer */
+
+/* The per-pixel render path: Renderer.render_area (renderer.py:90-106) for `sample_count` passes
+ * = Camera.get_ray (camera.py:39-50) + Renderer.raytrace (renderer.py:21-79) + environment lookup
+ * (scenes/room.py:15-22) + RenderResult.add_to_px (render_result.py:24-27), for every pixel of the
+ * rectangle.  Adds into `accum_dev` (device, float32 (W,H,3)); NULL = the context's own buffer.
+ * Asynchronous on `stream`; rt_synchronize waits. */
+int rt_render(rt_ctx *ctx, const rt_render_params *params, float *accum_dev, void *stream);
+int rt_synchronize(rt_ctx *ctx, void *stream);
+
+/* Renderer.stop_render (renderer.py:149-150): later rt_render calls return RT_ERR_STOPPED until
+ * rt_clear_stop. */
+int rt_request_stop(rt_ctx *ctx);
+int rt_clear_stop(rt_ctx *ctx);
+
+int rt_get_stats(rt_ctx *ctx, rt_stats *out);   /* cumulative since rt_reset_stats; synchronises */
+int rt_reset_stats(rt_ctx *ctx);
+
+/* Known-answer hook for the counter-based RNG the kernels use (no upstream counterpart: upstream
+ * draws from global MT19937 streams, renderer.py:62,64, vec3.py:14-16, camera.py:46-47).
+ * out[i] = the i-th uniform of path (pixel, sample) under `seed`, computed ON THE DEVICE. */
+int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t seed, int32_t n, float *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACING_AMD_H */

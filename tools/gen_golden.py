@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the UNMODIFIED upstream renderer and records what it computes.
+
+Runs only in the build container, where the upstream tree is mounted read-only at
+/root/reference.  Upstream needs ``pygame``, which is not installed here; ``tools/refshim`` puts a
+minimal stand-in (Vector3 arithmetic in plain doubles, PIL-backed image loading) on ``sys.path``
+so that upstream's own modules import and run.  Nothing from the upstream tree is copied: only
+inputs (packed scene tables, the decoded sky image) and outputs (hits, rays, radiance) are written,
+as compressed ``.npz`` / ``.json`` under tests/golden/.
+
+Same-sample-sequence trick: upstream draws from ``random.random`` (camera.py:46-47) and
+``np.random.random`` (renderer.py:62,64; vec3.py:14-16), looked up as module attributes at call
+time.  Before each path both are replaced by one stream that returns Philox4x32-10 uniforms keyed by
+(pixel, sample, seed) in sequential draw order — the very sequence the oracle and the HIP kernels
+generate internally.
+
+usage:  python tools/gen_golden.py {kat,scenes,rays,room_image,spheres_image,all} [--procs N]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import random
+import sys
+import time
+from multiprocessing import Pool
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(REPO, "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REPO, "tools", "refshim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+SEED_SCENE = 7          # np.random / random seed used to BUILD random_spheres
+SEED_RENDER = 0x5EED1234ABCD  # Philox seed of the golden renders
+
+_M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+_MASK = 0xFFFFFFFF
+
+
+def philox4x32_10(ctr, key):
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    for _ in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & _MASK, p1 & _MASK, ((p0 >> 32) ^ c3 ^ k1) & _MASK, p0 & _MASK
+        k0 = (k0 + _W0) & _MASK
+        k1 = (k1 + _W1) & _MASK
+    return c0, c1, c2, c3
+
+
+class PathStream:
+    """Callable returning the k-th uniform of path (pixel, sample) on the k-th call."""
+
+    def __init__(self, pixel: int, sample: int, seed: int):
+        self.key = ((pixel ^ (seed & _MASK)) & _MASK, (sample ^ (seed >> 32)) & _MASK)
+        self.k = 0
+        self._blk = -1
+        self._words = None
+
+    def __call__(self, *a, **kw):
+        k = self.k
+        self.k = k + 1
+        b = k >> 2
+        if b != self._blk:
+            self._words = philox4x32_10((b, 0, 0, 0), self.key)
+            self._blk = b
+        return float(self._words[k & 3] >> 8) * (1.0 / 16777216.0)
+
+
+_NP_RANDOM_ORIG = np.random.random
+_PY_RANDOM_ORIG = random.random
+
+
+def install_stream(stream):
+    np.random.random = stream
+    random.random = stream
+
+
+def restore_generators():
+    np.random.random = _NP_RANDOM_ORIG
+    random.random = _PY_RANDOM_ORIG
+
+
+def enter_reference():
+    os.chdir(REF)  # upstream scenes open ./assets/... relative paths
+
+
+def build_scene(which: str):
+    enter_reference()
+    restore_generators()  # scene construction must draw from the seeded global generators
+    np.random.seed(SEED_SCENE)
+    random.seed(SEED_SCENE)
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):  # random_spheres prints per sphere
+        if which == "room":
+            import scenes.room as mod
+        else:
+            import scenes.random_spheres as mod
+        scene = mod.get_scene()
+    return scene
+
+
+def pixel_uv(x, y, W, H):
+    aspect = H / W
+    return (x + 0.5) / W * 2 - 1, (y + 0.5) / H * 2 * aspect - aspect
+
+
+# ---------------------------------------------------------------------------------------------
+def hit_identity(scene, ray, hit):
+    """(object index, primitive id) of an upstream HitInfo: face index for meshes, 0/1 = near/far
+    root for spheres.  HitInfo only carries ``obj`` (hit_info.py:20), so the id is re-derived with
+    upstream's own per-primitive routines."""
+    from src.core.util import quadratic_formula
+
+    oi = next(i for i, o in enumerate(scene.objects) if o is hit.obj)
+    obj = hit.obj
+    if hasattr(obj, "radius"):
+        ro = ray.origin - obj.origin
+        a = ray.direction.dot(ray.direction)
+        b = 2 * ro.dot(ray.direction)
+        c = ro.dot(ro) - obj.radius ** 2
+        t1, t2 = quadratic_formula(a, b, c)
+        if t1 > 1e-10 and hit.depth == t1:
+            return oi, 0
+        assert hit.depth == t2
+        return oi, 1
+    for fi, face in enumerate(obj.triangles):
+        info = obj.intersect_tri(face, ray)
+        if info.hit and info.depth > 1e-10 and info.depth == hit.depth:
+            return oi, fi
+    raise AssertionError("hit not reproduced")
+
+
+def trace_recorded(renderer, scene, ray, records):
+    """Run upstream's raytrace while recording every Scene.intersect call it makes."""
+    orig = scene.intersect
+
+    def spy(r):
+        hits = orig(r)
+        rec = {"o": tuple(r.origin), "d": tuple(r.direction), "inside": bool(r.inside), "n_hits": len(hits)}
+        if hits:
+            h = hits[0]
+            oi, pi = hit_identity(scene, r, h)
+            rec.update(obj=oi, prim=pi, t=h.depth, n=tuple(h.normal), pos=tuple(h.pos))
+        else:
+            rec.update(obj=-1, prim=-1, t=math.inf, n=(0.0, 0.0, 0.0), pos=(0.0, 0.0, 0.0))
+        records.append(rec)
+        return hits
+
+    scene.intersect = spy
+    try:
+        from src.core import Vec3
+
+        return renderer.raytrace(ray, incoming_light=Vec3(0), ray_color=Vec3(1))
+    finally:
+        scene.intersect = orig
+
+
+def render_paths(which, W, H, spp, bounces, xs, record_rays=False, seed=SEED_RENDER):
+    """Upstream radiance of every (x in xs, y, sample): returns (rgb[len(xs),H,spp,3], status, recs)."""
+    scene = build_scene(which)
+    from src.raytracing import Renderer, RenderSettings
+
+    r = Renderer()
+    r.init_render(RenderSettings(scene, W, H, spp, bounces))
+    out = np.zeros((len(xs), H, spp, 3), dtype=np.float64)
+    status = np.zeros((len(xs), H, spp), dtype=np.int8)  # 0 ok, 1 upstream raised
+    ndraws = np.zeros((len(xs), H, spp), dtype=np.int16)
+    recs = []
+    for ix, x in enumerate(xs):
+        for y in range(H):
+            u, v = pixel_uv(x, y, W, H)
+            for s in range(spp):
+                stream = PathStream(x * H + y, s, seed)
+                install_stream(stream)
+                try:
+                    ray = scene.camera.get_ray(u, v)
+                    if record_rays:
+                        seg = []
+                        col = trace_recorded(r, scene, ray, seg)
+                        for j, rec in enumerate(seg):
+                            rec.update(x=x, y=y, s=s, seg=j)
+                        recs.extend(seg)
+                    else:
+                        col = r.raytrace(ray)
+                    out[ix, y, s] = tuple(col)
+                except (IndexError, ValueError):
+                    status[ix, y, s] = 1
+                ndraws[ix, y, s] = stream.k
+    return out, status, ndraws, recs
+
+
+def _worker(args):
+    which, W, H, spp, bounces, xs = args
+    out, status, ndraws, _ = render_paths(which, W, H, spp, bounces, xs)
+    return xs, out, status, ndraws
+
+
+def render_image_parallel(which, W, H, spp, bounces, procs):
+    cols = list(range(W))
+    chunks = [cols[i::procs * 4] for i in range(procs * 4)]
+    chunks = [c for c in chunks if c]
+    per_path = np.zeros((W, H, spp, 3), dtype=np.float64)
+    status = np.zeros((W, H, spp), dtype=np.int8)
+    ndraws = np.zeros((W, H, spp), dtype=np.int16)
+    t0 = time.time()
+    with Pool(procs) as pool:
+        for i, (xs, out, st, nd) in enumerate(pool.imap_unordered(
+                _worker, [(which, W, H, spp, bounces, c) for c in chunks])):
+            per_path[xs] = out
+            status[xs] = st
+            ndraws[xs] = nd
+            print(f"  [{which}] chunk {i + 1}/{len(chunks)}  {time.time() - t0:.0f}s", flush=True)
+    return per_path, status, ndraws
+
+
+# ---------------------------------------------------------------------------------------------
+def cmd_scenes():
+    from raytracing_amd.backend.packer import pack_scene
+
+    os.makedirs(GOLD, exist_ok=True)
+    sky_saved = False
+    for which in ("room", "random_spheres"):
+        scene = build_scene(which)
+        p = pack_scene(scene, build_bvh=False)
+        if not sky_saved:
+            np.savez_compressed(os.path.join(GOLD, "skybox1_rgb8.npz"), rgb=p.sky_rgb)
+            sky_saved = True
+        name = "room" if which == "room" else f"random_spheres_seed{SEED_SCENE}"
+        p.save(os.path.join(GOLD, f"scene_{name}.npz"), with_sky=False)
+        print(which, "objects", p.n_objects, "spheres", p.n_spheres, "tris", p.n_tris, "sky_scale", p.sky_scale)
+
+
+def cmd_kat():
+    """Known answers of upstream's per-function arithmetic (single calls, no randomness)."""
+    scene = build_scene("room")
+    from src.core import Ray, Vec3
+    from src.mesh import Sphere
+    from src.core import Material
+    from src.raytracing import util as rutil
+
+    kat = {"philox": [], "camera_room_1080p": [], "room_hits": [], "sphere": [], "shade": [], "sky": [], "aabb": []}
+    for ctr, key in (((0, 0, 0, 0), (0, 0)), ((_MASK,) * 4, (_MASK,) * 2),
+                     ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0))):
+        kat["philox"].append({"ctr": ctr, "key": key, "out": philox4x32_10(ctr, key)})
+    W, H = 1920, 1080
+    for (x, y) in ((0, 0), (959, 539), (1919, 1079), (1234, 321), (7, 1000), (1500, 15)):
+        u, v = pixel_uv(x, y, W, H)
+        ray = scene.camera.get_ray(u, v)
+        hits = scene.intersect(ray)
+        e = {"x": x, "y": y, "u": u, "v": v, "o": tuple(ray.origin), "d": tuple(ray.direction), "n_hits": len(hits)}
+        if hits:
+            oi, pi = hit_identity(scene, ray, hits[0])
+            e.update(obj=oi, prim=pi, t=hits[0].depth, n=tuple(hits[0].normal), pos=tuple(hits[0].pos))
+        kat["camera_room_1080p"].append(e)
+    ray = Ray(Vec3(0, 0, -2), Vec3(0, 0, 1))
+    hits = scene.intersect(ray)
+    kat["room_hits"].append({"o": (0, 0, -2), "d": (0, 0, 1), "all": [
+        {"obj": hit_identity(scene, ray, h)[0] if i == 0 else next(j for j, o in enumerate(scene.objects) if o is h.obj),
+         "t": h.depth, "n": tuple(h.normal)} for i, h in enumerate(hits)]})
+    s = Sphere(Material.default_material(), Vec3(1, 2, 3), 2)
+    for o, d in (((-4, 2.5, 1), tuple(Vec3(0.9, -0.1, 0.3).normalize())),):
+        hs = s.intersect(Ray(Vec3(*o), Vec3(*d)))
+        kat["sphere"].append({"c": (1, 2, 3), "r": 2, "o": o, "d": d, "hits": [{"t": h.depth, "n": tuple(h.normal), "pos": tuple(h.pos)} for h in hs]})
+    s1 = Sphere(Material.default_material(), Vec3(0), 1)
+    hs = s1.intersect(Ray(Vec3(-3, 1, 0), Vec3(1, 0, 0)))
+    kat["sphere"].append({"c": (0, 0, 0), "r": 1, "o": (-3, 1, 0), "d": (1, 0, 0), "hits": [{"t": h.depth, "n": tuple(h.normal), "pos": tuple(h.pos)} for h in hs]})
+    rng = np.random.RandomState(11)
+    for _ in range(24):
+        d = Vec3(*rng.uniform(-1, 1, 3)).normalize()
+        n = Vec3(*rng.uniform(-1, 1, 3)).normalize()
+        if rng.rand() < 0.5 and d.dot(n) > 0:
+            n = -n
+        ior = float(rng.choice([1.0, 1.4, 1.45]))
+        eta = float(rng.choice([ior, 1 / ior]))
+        kat["shade"].append({"d": tuple(d), "n": tuple(n), "ior": ior, "eta": eta,
+                             "schlick": rutil.schlick_approximation(-d, n, ior),
+                             "refract": tuple(rutil.refract(d, n, eta)),
+                             "reflect": tuple(d.reflect(n))})
+    d = Vec3(0.6, -0.8, 0)
+    n = Vec3(0, 1, 0)
+    kat["shade"].append({"d": tuple(d), "n": tuple(n), "ior": 1.45, "eta": 1 / 1.45,
+                         "schlick": rutil.schlick_approximation(-d, n, 1.45),
+                         "refract": tuple(rutil.refract(d, n, 1 / 1.45)), "reflect": tuple(d.reflect(n))})
+    for vec in ((1, 0, 0), (0, 1, 0), tuple(Vec3(-1, 0, 1e-9).normalize()), tuple(Vec3(-1, 0, -1e-9).normalize()),
+                tuple(Vec3(0.3, -0.5, 0.2).normalize()), tuple(Vec3(-0.2, 0.7, -0.4).normalize())):
+        uv = rutil.vec_to_sky_coords(Vec3(*vec))
+        e = {"d": vec, "uv": (float(uv[0]), float(uv[1]))}
+        try:
+            e["room_env"] = tuple(scene.get_environment(Ray(Vec3(0), Vec3(*vec))))
+        except (IndexError, ValueError) as ex:
+            e["room_env_raises"] = type(ex).__name__
+        kat["sky"].append(e)
+    lamp = next(o for o in scene.objects if getattr(o, "name", "") == "lamp")
+    kat["aabb"].append({"mesh": "lamp", "bb": [tuple(lamp.bounding_box[0]), tuple(lamp.bounding_box[1])],
+                        "cases": [{"o": o, "d": d, "hit": bool(lamp.intersect_aabb(Ray(Vec3(*o), Vec3(*d))))}
+                                  for o, d in (((0, 0.95, -2), (0, 0, 1)), ((0, 0, -2), (0, 0, 1)),
+                                               ((0.2, -1.5, 0.1), (0, 1, 0)), ((0.2, -1.5, 0.1), (0.1, 1, 0)))]})
+    os.makedirs(GOLD, exist_ok=True)
+    with open(os.path.join(GOLD, "kat.json"), "w") as fh:
+        json.dump(kat, fh, indent=1)
+    print("kat.json written")
+
+
+def _recs_to_npz(recs, path, meta):
+    n = len(recs)
+    arr = lambda k, dt, w=None: np.array([r[k] for r in recs], dtype=dt).reshape((n,) if w is None else (n, w))
+    np.savez_compressed(
+        path, org=arr("o", np.float64, 3), dir=arr("d", np.float64, 3), inside=arr("inside", np.int8),
+        obj=arr("obj", np.int32), prim=arr("prim", np.int32), t=arr("t", np.float64), normal=arr("n", np.float64, 3),
+        pos=arr("pos", np.float64, 3), n_hits=arr("n_hits", np.int32), x=arr("x", np.int32), y=arr("y", np.int32),
+        s=arr("s", np.int32), seg=arr("seg", np.int32), meta=np.array(json.dumps(meta)))
+
+
+def cmd_rays():
+    """Per-segment ray dumps: every Scene.intersect call of a few thousand seeded paths."""
+    for which, W, H, spp, bounces, stride in (("room", 96, 54, 2, 8, 1), ("random_spheres", 96, 54, 4, 8, 1)):
+        t0 = time.time()
+        xs = list(range(0, W, stride))
+        out, status, ndraws, recs = render_paths(which, W, H, spp, bounces, xs, record_rays=True)
+        meta = dict(scene=which, W=W, H=H, spp=spp, bounces=bounces, seed=SEED_RENDER, scene_seed=SEED_SCENE)
+        _recs_to_npz(recs, os.path.join(GOLD, f"rays_{which}.npz"), meta)
+        np.savez_compressed(os.path.join(GOLD, f"paths_{which}.npz"), rgb=out, status=status, ndraws=ndraws,
+                            meta=np.array(json.dumps(meta)))
+        print(which, "rays", len(recs), "paths", out.shape[0] * H * spp, "raised", int(status.sum()), f"{time.time() - t0:.1f}s")
+
+
+def cmd_image(which, W, H, spp, bounces, procs, tag):
+    t0 = time.time()
+    per_path, status, ndraws = render_image_parallel(which, W, H, spp, bounces, procs)
+    meta = dict(scene=which, W=W, H=H, spp=spp, bounces=bounces, seed=SEED_RENDER, scene_seed=SEED_SCENE,
+                seconds=time.time() - t0, procs=procs)
+    arr = per_path.sum(axis=2)  # RenderResult.arr: un-normalised sum over passes
+    np.savez_compressed(os.path.join(GOLD, f"image_{tag}.npz"), arr=arr, per_path=per_path.astype(np.float32),
+                        status=status, ndraws=ndraws, meta=np.array(json.dumps(meta)))
+    print(tag, "done", f"{time.time() - t0:.0f}s", "raised", int(status.sum()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["kat", "scenes", "rays", "room_image", "spheres_image", "all"])
+    ap.add_argument("--procs", type=int, default=6)
+    a = ap.parse_args()
+    if a.what in ("scenes", "all"):
+        cmd_scenes()
+    if a.what in ("kat", "all"):
+        cmd_kat()
+    if a.what in ("rays", "all"):
+        cmd_rays()
+    if a.what in ("room_image", "all"):
+        cmd_image("room", 96, 54, 8, 8, a.procs, "room_96x54_8spp_8b")
+    if a.what in ("spheres_image", "all"):
+        cmd_image("random_spheres", 320, 180, 16, 4, a.procs, "random_spheres_320x180_16spp_4b")
+
+
+if __name__ == "__main__":
+    main()
