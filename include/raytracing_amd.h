@@ -109,7 +109,8 @@ typedef struct rt_stats {
     uint64_t rays;                 /* closest-hit queries = Scene.intersect calls (scene.py:23) */
     uint64_t paths;                /* top-level raytrace calls (renderer.py:105) */
     uint64_t sphere_tests, tri_tests, aabb_tests, bvh_node_tests; /* float32 filter tests executed */
-    uint64_t exact_rays;           /* rays re-evaluated by the double-precision exact scan */
+    uint64_t exact_rays;           /* rays answered by the double-precision scan of the whole scene */
+    uint64_t refined_hits;         /* hits whose winning primitive was re-evaluated in double precision */
     uint64_t sky_lookups, shaded_hits;
     double kernel_ms;              /* device time of the dominant kernel, summed over launches */
     uint64_t launches;
@@ -133,10 +134,13 @@ int rt_set_scene(rt_ctx *ctx, const rt_scene_desc *scene);
  * (mesh.py:61-143).  Host arrays.  obj = index into scene.objects or -1; prim = face index inside
  * the mesh, or 0/1 = near/far root for a sphere; t, normal (unit, as the object returns it, not
  * flipped), pos are doubles.  `origin_prim` (may be NULL) marks rays that start ON a primitive as
- * bounce rays do: value = global primitive id as returned in `gprim`, -1 = none. */
+ * bounce rays do: value = global primitive id as returned in `gprim` (sphere index, or n_spheres +
+ * triangle index), -1 = none; NULL gives upstream's semantics unchanged.  `how` (may be NULL)
+ * reports which code produced each answer: 0 = float32 filter alone, 1 = winning primitive
+ * re-evaluated in double precision, 2 = whole scene re-evaluated in double precision. */
 int rt_intersect_batch(rt_ctx *ctx, int64_t n, const double *org, const double *dir,
                        const int32_t *origin_prim, int32_t *obj, int32_t *prim, int32_t *gprim,
-                       double *t, double *normal, double *pos);
+                       int32_t *how, double *t, double *normal, double *pos);
 
 /* Accumulation buffer: RenderResult.arr (render_result.py:14,24-27).  The context owns one
  * float32 (W,H,3) device buffer, (re)allocated by rt_accum_resize and zeroed. */
@@ -163,8 +167,9 @@ int rt_reset_stats(rt_ctx *ctx);
 
 /* Known-answer hook for the counter-based RNG the kernels use (no upstream counterpart: upstream
  * draws from global MT19937 streams, renderer.py:62,64, vec3.py:14-16, camera.py:46-47).
- * out[i] = the i-th uniform of path (pixel, sample) under `seed`, computed ON THE DEVICE. */
-int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t seed, int32_t n, float *out_host);
+ * out[5*s + i] = uniform i (0..4) of segment s of path (pixel, sample) under `seed`, computed ON THE
+ * DEVICE: one Philox4x32-10 block per path segment, five 24-bit fields each. */
+int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t seed, int32_t n_segments, float *out_host);
 
 #ifdef __cplusplus
 }

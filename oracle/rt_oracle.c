@@ -13,8 +13,9 @@
  * oracle/README.md: "what pins this oracle").
  *
  * Random numbers: upstream draws from global MT19937 streams; this restatement (and the kernels)
- * instead take the k-th draw of path (pixel, sample) from Philox4x32-10, in upstream's draw ORDER
- * (camera.py:46-47 first, then renderer.py:62,64 and vec3.py:14-16 per bounce).  The golden
+ * instead take the draws of path (pixel, sample) from Philox4x32-10, one 128-bit block per path
+ * segment, in upstream's draw ORDER (camera.py:46-47 first, then renderer.py:62,64 and
+ * vec3.py:14-16 per bounce; see orc_uniform).  The golden
  * generator injects the very same stream into the upstream code, so both sides see one sequence.
  *
  * Deliberate deviations from upstream (each counted in orc_counters):
@@ -77,27 +78,45 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* k-th uniform of path (pixel, sample): word k&3 of block k>>2, top 24 bits, in [0,1). */
-double orc_uniform(uint32_t pixel, uint32_t sample, uint64_t seed, uint32_t k) {
-    uint32_t ctr[4] = {k >> 2, 0, 0, 0};
+/* Uniform i (0..4) of segment c of path (pixel, sample): the i-th 24-bit field of the 128-bit
+ * block Philox4x32-10(counter = (c,0,0,0), key = (pixel ^ seed_lo, sample ^ seed_hi)), taken from
+ * the most significant end: x[31:8], x[7:0]:y[31:16], y[15:0]:z[31:24], z[23:0], w[31:8].
+ * Segment 0 feeds the camera (depth-of-field jitter, camera.py:46-47); segment j+1 feeds the
+ * shading decision after the j-th Scene.intersect call of the path (renderer.py:62,64 and
+ * vec3.py:14-16 draw at most five numbers there), in upstream's call order. */
+double orc_uniform(uint32_t pixel, uint32_t sample, uint64_t seed, uint32_t c, uint32_t i) {
+    uint32_t ctr[4] = {c, 0, 0, 0};
     uint32_t key[2] = {pixel ^ (uint32_t)seed, sample ^ (uint32_t)(seed >> 32)};
     uint32_t o[4];
     orc_philox4x32_10(ctr, key, o);
-    return (double)(o[k & 3] >> 8) * (1.0 / 16777216.0);
+    uint32_t f;
+    switch (i) {
+    case 0: f = o[0] >> 8; break;
+    case 1: f = ((o[0] & 0xFFu) << 16) | (o[1] >> 16); break;
+    case 2: f = ((o[1] & 0xFFFFu) << 8) | (o[2] >> 24); break;
+    case 3: f = o[2] & 0xFFFFFFu; break;
+    default: f = o[3] >> 8; break;
+    }
+    return (double)f * (1.0 / 16777216.0);
 }
 
 typedef struct {
-    uint32_t pixel, sample; uint64_t seed; uint32_t k;
-    const double *inject; int n_inject; /* optional explicit stream (tests) */
+    uint32_t pixel, sample; uint64_t seed;
+    uint32_t c, i;      /* current segment and the next field inside it */
+    uint32_t total;     /* draws consumed by the path so far */
+    const double *inject; int n_inject; /* optional explicit stream (tests), consumed sequentially */
 } draw_stream;
+
+static inline void begin_segment(draw_stream *s, uint32_t c) { s->c = c; s->i = 0; }
 
 static inline double next_draw(draw_stream *s) {
     if (s->inject) {
-        double v = (int)s->k < s->n_inject ? s->inject[s->k] : 0.5;
-        s->k++;
+        double v = (int)s->total < s->n_inject ? s->inject[s->total] : 0.5;
+        s->total++;
         return v;
     }
-    return orc_uniform(s->pixel, s->sample, s->seed, s->k++);
+    s->total++;
+    return orc_uniform(s->pixel, s->sample, s->seed, s->c, s->i++);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -304,7 +323,7 @@ static void camera_ray(const rt_scene_desc *s, double u, double v, draw_stream *
 }
 void orc_camera_ray(const rt_scene_desc *s, double u, double v, const double *draws, int n_draws,
                     double o[3], double d[3]) {
-    draw_stream rng = {0, 0, 0, 0, draws, n_draws};
+    draw_stream rng = {0, 0, 0, 0, 0, 0, draws, n_draws};
     v3 oo, dd;
     camera_ray(s, u, v, &rng, &oo, &dd);
     o[0] = oo.x; o[1] = oo.y; o[2] = oo.z; d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
@@ -340,6 +359,7 @@ static v3 trace_path(const rt_scene_desc *s, v3 o, v3 d, int max_bounces, draw_s
         hit_rec h;
         (*rays)++;
         scene_intersect(s, o, d, &h); /* renderer.py:32 */
+        begin_segment(rng, (uint32_t)depth + 1);
         if (tr) {
             int i = tr->n++;
             tr->org[3 * i] = o.x; tr->org[3 * i + 1] = o.y; tr->org[3 * i + 2] = o.z;
@@ -392,7 +412,7 @@ void orc_trace_pixel(const rt_scene_desc *s, int W, int H, int x, int y, uint32_
                      int32_t *seg_prim, double *seg_t, int32_t *n_seg) {
     double u, v;
     pixel_uv(x, y, W, H, &u, &v);
-    draw_stream rng = {(uint32_t)(x * H + y), sample, seed, 0, inject, n_inject};
+    draw_stream rng = {(uint32_t)(x * H + y), sample, seed, 0, 0, 0, inject, n_inject};
     v3 o, d;
     camera_ray(s, u, v, &rng, &o, &d);
     seg_trace tr = {seg_org, seg_dir, seg_inside, seg_obj, seg_prim, seg_t, 0};
@@ -400,7 +420,7 @@ void orc_trace_pixel(const rt_scene_desc *s, int W, int H, int x, int y, uint32_
     v3 L = trace_path(s, o, d, max_bounces, &rng, &r, seg_org ? &tr : NULL);
     rgb[0] = L.x; rgb[1] = L.y; rgb[2] = L.z;
     if (rays) *rays = r;
-    if (n_draws) *n_draws = (int32_t)rng.k;
+    if (n_draws) *n_draws = (int32_t)rng.total;
     if (n_seg) *n_seg = tr.n;
 }
 
@@ -420,7 +440,7 @@ void orc_render(const rt_scene_desc *s, int W, int H, int x0, int x1, int y0, in
             for (int sidx = sample_begin; sidx < sample_begin + sample_count; ++sidx) {
                 double u, v;
                 pixel_uv(x, y, W, H, &u, &v);
-                draw_stream rng = {(uint32_t)(x * H + y), (uint32_t)sidx, seed, 0, NULL, 0};
+                draw_stream rng = {(uint32_t)(x * H + y), (uint32_t)sidx, seed, 0, 0, 0, NULL, 0};
                 v3 o, d;
                 camera_ray(s, u, v, &rng, &o, &d);
                 uint64_t r = 0;

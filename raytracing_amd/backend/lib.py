@@ -1,0 +1,194 @@
+"""ctypes binding of the C ABI in include/raytracing_amd.h (``_rt_hip.so``, built by
+``python -m raytracing_amd.backend.build`` or ``__graft_entry__.build()``).
+
+There is no CPU implementation behind these calls: if the shared library is missing, or no
+gfx950 device is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .packer import PackedScene, RtSceneDesc
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_rt_hip.so")
+
+STATUS_NAMES = {0: "RT_OK", 1: "RT_ERR_INVALID_ARG", 2: "RT_ERR_NO_SCENE", 3: "RT_ERR_HIP", 4: "RT_ERR_NO_DEVICE",
+                5: "RT_ERR_STOPPED", 6: "RT_ERR_UNSUPPORTED"}
+RT_ERR_STOPPED = 5
+
+# every symbol include/raytracing_amd.h declares
+EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
+           "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
+           "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms"]
+
+
+class RtRenderParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
+                ("x0", C.c_int32), ("x1", C.c_int32), ("y0", C.c_int32), ("y1", C.c_int32),
+                ("sample_begin", C.c_int32), ("sample_count", C.c_int32), ("max_bounces", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("sphere_tests", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("aabb_tests", C.c_uint64), ("bvh_node_tests", C.c_uint64), ("exact_rays", C.c_uint64),
+                ("refined_hits", C.c_uint64), ("sky_lookups", C.c_uint64), ("shaded_hits", C.c_uint64),
+                ("kernel_ms", C.c_double), ("launches", C.c_uint64)]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class BackendError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load ``_rt_hip.so`` and declare the prototypes.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} is missing: build the HIP library first (python -m raytracing_amd.backend.build). "
+                           "This package has no CPU render path.")
+    lib = C.CDLL(p)
+    vp, dp, ip, fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    lib.rt_abi_version.restype = C.c_int
+    lib.rt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.rt_destroy.argtypes = [vp]
+    lib.rt_last_error.argtypes = [vp]
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_set_scene.argtypes = [vp, C.POINTER(RtSceneDesc)]
+    lib.rt_intersect_batch.argtypes = [vp, C.c_int64, dp, dp, ip, ip, ip, ip, ip, dp, dp, dp]
+    lib.rt_accum_resize.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.rt_accum_clear.argtypes = [vp]
+    lib.rt_accum_device_ptr.argtypes = [vp]
+    lib.rt_accum_device_ptr.restype = vp
+    lib.rt_accum_read.argtypes = [vp, fp]
+    lib.rt_render.argtypes = [vp, C.POINTER(RtRenderParams), vp, vp]
+    lib.rt_synchronize.argtypes = [vp, vp]
+    lib.rt_request_stop.argtypes = [vp]
+    lib.rt_clear_stop.argtypes = [vp]
+    lib.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
+    lib.rt_reset_stats.argtypes = [vp]
+    lib.rt_debug_uniforms.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int32, fp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class HipBackend:
+    """One context on one GPU: scene upload, closest-hit queries, rendering into a device buffer."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.rt_create(device, C.byref(h))
+        if st != 0:
+            raise BackendError(st, (self.lib.rt_last_error(None) or b"").decode())
+        self.handle = h
+        self.device = device
+        self._scene_keepalive = None
+        self.size = None
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, st: int) -> None:
+        if st != 0:
+            raise BackendError(st, (self.lib.rt_last_error(self.handle) or b"").decode())
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.rt_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scene ----------------------------------------------------------------------------------
+    def set_scene(self, packed: PackedScene) -> None:
+        d = packed.desc()
+        self._check(self.lib.rt_set_scene(self.handle, C.byref(d)))
+        self._scene_keepalive = packed
+
+    # -- closest hit ----------------------------------------------------------------------------
+    def intersect(self, origins, directions, origin_prim=None) -> dict:
+        org = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        drs = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+        n = org.shape[0]
+        if drs.shape[0] != n:
+            raise ValueError("origins and directions differ in length")
+        out = dict(obj=np.empty(n, np.int32), prim=np.empty(n, np.int32), gprim=np.empty(n, np.int32),
+                   how=np.empty(n, np.int32), t=np.empty(n, np.float64), normal=np.empty((n, 3), np.float64),
+                   pos=np.empty((n, 3), np.float64))
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        op = None
+        if origin_prim is not None:
+            origin_prim = np.ascontiguousarray(origin_prim, dtype=np.int32)
+            op = origin_prim.ctypes.data_as(ip)
+        self._check(self.lib.rt_intersect_batch(
+            self.handle, n, org.ctypes.data_as(dp), drs.ctypes.data_as(dp), op,
+            out["obj"].ctypes.data_as(ip), out["prim"].ctypes.data_as(ip), out["gprim"].ctypes.data_as(ip),
+            out["how"].ctypes.data_as(ip), out["t"].ctypes.data_as(dp), out["normal"].ctypes.data_as(dp),
+            out["pos"].ctypes.data_as(dp)))
+        return out
+
+    # -- accumulation buffer --------------------------------------------------------------------
+    def resize(self, width: int, height: int) -> None:
+        self._check(self.lib.rt_accum_resize(self.handle, width, height))
+        self.size = (width, height)
+
+    def clear(self) -> None:
+        self._check(self.lib.rt_accum_clear(self.handle))
+
+    def accum_ptr(self) -> int:
+        return int(self.lib.rt_accum_device_ptr(self.handle) or 0)
+
+    def read(self) -> np.ndarray:
+        w, h = self.size
+        out = np.empty((w, h, 3), dtype=np.float32)
+        self._check(self.lib.rt_accum_read(self.handle, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    # -- render ---------------------------------------------------------------------------------
+    def render(self, width: int, height: int, sample_begin: int, sample_count: int, max_bounces: int, seed: int,
+               rect=None, accum_ptr: int = 0, stream: int = 0) -> None:
+        x0, x1, y0, y1 = rect if rect is not None else (0, width, 0, height)
+        p = RtRenderParams(C.sizeof(RtRenderParams), width, height, x0, x1, y0, y1, sample_begin, sample_count,
+                           max_bounces, seed & 0xFFFFFFFFFFFFFFFF)
+        self._check(self.lib.rt_render(self.handle, C.byref(p), C.c_void_p(accum_ptr or None), C.c_void_p(stream or None)))
+
+    def synchronize(self, stream: int = 0) -> None:
+        self._check(self.lib.rt_synchronize(self.handle, C.c_void_p(stream or None)))
+
+    def request_stop(self) -> None:
+        self.lib.rt_request_stop(self.handle)
+
+    def clear_stop(self) -> None:
+        self.lib.rt_clear_stop(self.handle)
+
+    def stats(self) -> dict:
+        s = RtStats()
+        self._check(self.lib.rt_get_stats(self.handle, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self) -> None:
+        self._check(self.lib.rt_reset_stats(self.handle))
+
+    def debug_uniforms(self, pixel: int, sample: int, seed: int, n_segments: int) -> np.ndarray:
+        out = np.empty((n_segments, 5), dtype=np.float32)
+        self._check(self.lib.rt_debug_uniforms(self.handle, pixel, sample, seed, n_segments,
+                                               out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out

@@ -1,0 +1,574 @@
+// C ABI of the path-tracing backend (include/raytracing_amd.h): context, scene upload (double
+// tables -> float32 filter rows with error-bound constants), the closest-hit entry and the render
+// entry.  gfx950 only; built with -ffp-contract=off (the exact double-precision code must round
+// like upstream's Python floats, and the float32 code spells out every fused multiply-add).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracing_amd.h"
+#include "rt_exact.h"
+#include "rt_filter.h"
+#include "rt_render.h"
+#include "rt_scene.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, n ? n : 1);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T> hipError_t upload(const std::vector<T> &v) {
+        hipError_t e = ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    int n_cu = 256;
+    std::mutex mu;               // guards err and the host-side stats bookkeeping
+    std::string err;
+    std::atomic<int> stop{0};
+    bool has_scene = false;
+    DevScene S{};
+    bool has_tri = false, has_sph = false, det_cut = false;
+    DevBuf tri_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
+    DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri;
+    DevBuf accum; int acc_w = 0, acc_h = 0;
+    DevBuf partial, job_counter, stats;
+    std::vector<EventPair> timed;
+    double kernel_ms = 0; uint64_t launches = 0;
+};
+
+namespace {
+
+int fail(rt_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) { std::lock_guard<std::mutex> g(c->mu); c->err = buf; } else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail((c), RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct V3 { double x, y, z; };
+V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+double norm(V3 a) { return std::sqrt(dot(a, a)); }
+double norm1(V3 a) { return std::fabs(a.x) + std::fabs(a.y) + std::fabs(a.z); }
+
+// Largest float not above / smallest float not below a positive double (bounds must stay bounds).
+float up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; }
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char *rt_last_error(const rt_ctx *ctx) {
+    if (!ctx) return g_create_error.c_str();
+    return ctx->err.c_str();
+}
+
+int rt_create(int device_id, rt_ctx **out) {
+    if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_NO_DEVICE, "device %d out of range (%d visible)", device_id, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, RT_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    rt_ctx *c = new rt_ctx();
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    if (hipSetDevice(device_id) != hipSuccess || c->job_counter.ensure(256) != hipSuccess ||
+        c->stats.ensure(sizeof(unsigned long long) * kStatCount) != hipSuccess ||
+        hipMemset(c->stats.p, 0, sizeof(unsigned long long) * kStatCount) != hipSuccess) {
+        delete c;
+        return fail(nullptr, RT_ERR_HIP, "device %d: initial allocation failed", device_id);
+    }
+    *out = c;
+    return RT_OK;
+}
+
+int rt_destroy(rt_ctx *ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &e : ctx->timed) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete ctx;
+    return RT_OK;
+}
+
+int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
+    if (!c || !d) return fail(c, RT_ERR_INVALID_ARG, "rt_set_scene: NULL argument");
+    if (d->struct_size != sizeof(rt_scene_desc))
+        return fail(c, RT_ERR_INVALID_ARG, "rt_scene_desc.struct_size %u != %zu", d->struct_size, sizeof(rt_scene_desc));
+    if (d->n_objects < 0 || d->n_spheres < 0 || d->n_meshes < 0 || d->n_tris < 0)
+        return fail(c, RT_ERR_INVALID_ARG, "negative count in scene description");
+    if ((d->n_objects && (!d->obj_kind || !d->obj_index || !d->materials)) || (d->n_spheres && (!d->spheres || !d->sphere_obj)) ||
+        (d->n_meshes && (!d->mesh_aabb || !d->mesh_obj || !d->mesh_tri_begin)) || (d->n_tris && !d->tri_verts))
+        return fail(c, RT_ERR_INVALID_ARG, "NULL table with a non-zero count");
+    if (d->n_objects != d->n_spheres + d->n_meshes)
+        return fail(c, RT_ERR_INVALID_ARG, "n_objects %d != n_spheres %d + n_meshes %d", d->n_objects, d->n_spheres, d->n_meshes);
+    for (int i = 0; i < d->n_objects; ++i) {
+        int k = d->obj_kind[i], ix = d->obj_index[i];
+        if ((k != RT_OBJ_SPHERE && k != RT_OBJ_MESH) || ix < 0 || ix >= (k == RT_OBJ_SPHERE ? d->n_spheres : d->n_meshes))
+            return fail(c, RT_ERR_INVALID_ARG, "object %d: bad kind/index (%d, %d)", i, k, ix);
+    }
+    if (d->n_meshes && (d->mesh_tri_begin[0] != 0 || d->mesh_tri_begin[d->n_meshes] != d->n_tris))
+        return fail(c, RT_ERR_INVALID_ARG, "mesh_tri_begin does not span [0, n_tris]");
+    for (int m = 0; m < d->n_meshes; ++m)
+        if (d->mesh_tri_begin[m + 1] < d->mesh_tri_begin[m]) return fail(c, RT_ERR_INVALID_ARG, "mesh_tri_begin not monotone");
+    if (d->n_bvh_nodes > 0) return fail(c, RT_ERR_UNSUPPORTED, "BVH traversal kernels are not built yet; pass n_bvh_nodes = 0");
+    const long long n_gprim = (long long)d->n_spheres + d->n_tris;
+    if (n_gprim > 4096) return fail(c, RT_ERR_UNSUPPORTED, "%lld primitives: the brute-force kernels take at most 4096", n_gprim);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+
+    const V3 cam = {d->cam_pos[0], d->cam_pos[1], d->cam_pos[2]};
+    double scene_radius = norm1(cam);
+
+    // ---- triangles ---------------------------------------------------------------------------
+    std::vector<int> tri_mesh(d->n_tris, 0);
+    for (int m = 0; m < d->n_meshes; ++m)
+        for (int t = d->mesh_tri_begin[m]; t < d->mesh_tri_begin[m + 1]; ++t) tri_mesh[t] = m;
+    std::vector<TriRow> rows_live, rows_all(d->n_tris);
+    std::vector<TriAux> aux(d->n_tris);
+    bool any_det = false;
+    for (int t = 0; t < d->n_tris; ++t) {
+        const double *v = d->tri_verts + 9 * (size_t)t;
+        V3 a = {v[0], v[1], v[2]}, b = {v[3], v[4], v[5]}, cc = {v[6], v[7], v[8]};
+        V3 ab = sub(b, a), ac = sub(cc, a), N = cross(ab, ac);
+        double nl = norm(N);
+        TriRow r{}; TriAux x{};
+        const int m = tri_mesh[t];
+        x.obj = d->mesh_obj[m]; x.face = t - d->mesh_tri_begin[m]; x.mesh = m;
+        r.gprim = d->n_spheres + t;
+        // |det| = |d.N| <= |d||N|: with |d| <= 2 (longer rays use the exact code) a triangle with
+        // |N| < 4e-7 can never pass upstream's |det| >= 1e-6 cut, nor can a non-finite one.
+        const bool live = std::isfinite(nl) && nl >= 4e-7;
+        if (live) {
+            V3 e1 = cross(ac, N), e2 = cross(N, ab);
+            double n2 = nl * nl;
+            e1 = {e1.x / n2, e1.y / n2, e1.z / n2}; e2 = {e2.x / n2, e2.y / n2, e2.z / n2};
+            r.nx = (float)N.x; r.ny = (float)N.y; r.nz = (float)N.z; r.kn = (float)(-dot(N, a));
+            r.e1x = (float)e1.x; r.e1y = (float)e1.y; r.e1z = (float)e1.z; r.k1 = (float)(-dot(e1, a));
+            r.e2x = (float)e2.x; r.e2y = (float)e2.y; r.e2z = (float)e2.z; r.k2 = (float)(-dot(e2, a));
+            r.cb = up(32.0 * nl * std::max(norm(e1), norm(e2)));
+            r.ct = up(16.0 * nl);
+            const double noise = 16.0 * (double)kU * nl;
+            r.det_lo = (float)std::max(0.0, 1e-6 - noise) * (1.0f - 4.0f * kU);
+            x.det_hi = up(1e-6 + noise);
+            if (r.det_lo > 0) any_det = true;
+            x.nx = (float)(N.x / nl); x.ny = (float)(N.y / nl); x.nz = (float)(N.z / nl);
+            rows_live.push_back(r);
+            scene_radius = std::max({scene_radius, norm1(a), norm1(b), norm1(cc)});
+        } else {
+            // never a candidate; judged "undecided" if ever asked, so the exact code answers
+            r.nx = r.ny = r.nz = 0; r.kn = 1; r.k1 = r.k2 = -1; r.cb = 0; r.ct = 0; r.det_lo = INFINITY;
+            x.det_hi = INFINITY;
+        }
+        rows_all[t] = r; aux[t] = x;
+    }
+
+    // ---- spheres -----------------------------------------------------------------------------
+    std::vector<double> radii(d->n_spheres);
+    for (int s = 0; s < d->n_spheres; ++s) radii[s] = std::fabs(d->spheres[4 * (size_t)s + 3]);
+    double median_r = 0;
+    if (d->n_spheres >= 3) {
+        std::vector<double> tmp = radii;
+        std::nth_element(tmp.begin(), tmp.begin() + tmp.size() / 2, tmp.end());
+        median_r = tmp[tmp.size() / 2];
+    }
+    std::vector<SphRow> sph_small, sph_all(d->n_spheres);
+    std::vector<int32_t> big;
+    for (int s = 0; s < d->n_spheres; ++s) {
+        const double *p = d->spheres + 4 * (size_t)s;
+        V3 ctr = {p[0], p[1], p[2]};
+        double r = radii[s];
+        // Huge spheres (a ground "plane" of radius 1e5 under a camera a few units away) lose all
+        // float32 precision in |o-c|^2 - r^2; they are few, and are evaluated in double instead.
+        double gap = std::fabs(norm(sub(cam, ctr)) - r);
+        bool is_big = !(std::isfinite(r) && std::isfinite(norm1(ctr))) || (median_r > 0 && r > 64.0 * median_r) ||
+                      r > 64.0 * std::max(gap, 1e-3 * r);
+        SphRow row{};
+        row.cx = (float)ctr.x; row.cy = (float)ctr.y; row.cz = (float)ctr.z;
+        row.r2 = (float)(r * r); row.r = (float)r; row.cn = up(norm(ctr)); row.qs = 0; row.gprim = s;
+        sph_all[s] = row;
+        if (is_big) big.push_back(s);
+        else { sph_small.push_back(row); scene_radius = std::max(scene_radius, norm1(ctr) + 3.0 * r); }
+    }
+
+    // ---- materials, environment ---------------------------------------------------------------
+    std::vector<MatRow> mats(d->n_objects);
+    for (int i = 0; i < d->n_objects; ++i) {
+        const double *m = d->materials + 7 * (size_t)i;
+        double r0 = (1 - m[6]) / (1 + m[6]);
+        mats[i] = {(float)m[0], (float)m[1], (float)m[2], (float)m[3], (float)m[4], (float)m[5], (float)m[6], (float)(r0 * r0)};
+    }
+    std::vector<uint32_t> sky;
+    const bool has_sky = d->sky_rgb && d->sky_w > 0 && d->sky_h > 0;
+    if (has_sky) {
+        sky.resize((size_t)d->sky_w * d->sky_h);
+        for (size_t i = 0; i < sky.size(); ++i)
+            sky[i] = (uint32_t)d->sky_rgb[3 * i] | ((uint32_t)d->sky_rgb[3 * i + 1] << 8) | ((uint32_t)d->sky_rgb[3 * i + 2] << 16);
+    }
+
+    // ---- upload --------------------------------------------------------------------------------
+    std::vector<double> tri64(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
+    std::vector<double> sph64(d->spheres, d->spheres + 4 * (size_t)d->n_spheres);
+    std::vector<double> aabb64(d->mesh_aabb, d->mesh_aabb + 6 * (size_t)d->n_meshes);
+    std::vector<int32_t> mtb(d->n_meshes + 1, 0);
+    for (int m = 0; m <= d->n_meshes && d->n_meshes; ++m) mtb[m] = d->mesh_tri_begin[m];
+    std::vector<int32_t> okind(d->obj_kind, d->obj_kind + d->n_objects), oindex(d->obj_index, d->obj_index + d->n_objects);
+    std::vector<int32_t> sobj(d->sphere_obj, d->sphere_obj + d->n_spheres);
+    HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
+    HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
+    HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));
+    HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
+    HIP_TRY(c, c->mesh_tri_begin.upload(mtb)); HIP_TRY(c, c->obj_kind.upload(okind)); HIP_TRY(c, c->obj_index.upload(oindex));
+    if (has_sky) HIP_TRY(c, c->sky.upload(sky));
+
+    DevScene &S = c->S;
+    S = DevScene{};
+    S.tri_rows = c->tri_rows.as<TriRow>(); S.n_tri_rows = (int)rows_live.size();
+    S.sph_rows = c->sph_rows.as<SphRow>(); S.n_sph_rows = (int)sph_small.size();
+    S.big_sph = c->big_sph.as<int32_t>(); S.n_big_sph = (int)big.size();
+    S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();
+    S.sph_by_id = c->sph_by_id.as<SphRow>(); S.sph_obj = c->sph_obj.as<int32_t>();
+    S.materials = c->materials.as<MatRow>();
+    S.tri64 = c->tri64.as<double>(); S.sph64 = c->sph64.as<double>(); S.aabb64 = c->aabb64.as<double>();
+    S.mesh_tri_begin = c->mesh_tri_begin.as<int32_t>(); S.obj_kind = c->obj_kind.as<int32_t>(); S.obj_index = c->obj_index.as<int32_t>();
+    S.n_objects = d->n_objects; S.n_spheres = d->n_spheres; S.n_tris = d->n_tris; S.n_meshes = d->n_meshes;
+    S.bvh = nullptr; S.n_bvh = 0; S.bvh_tri = nullptr;
+    S.scene_radius = up(scene_radius);
+    int bits = 5;
+    while ((1ll << bits) < n_gprim) ++bits;
+    S.key_mask = (1u << bits) - 1u;
+    S.any_det_cut = any_det;
+    for (int k = 0; k < 3; ++k) {
+        S.cam_pos[k] = (float)d->cam_pos[k]; S.cam_right[k] = (float)d->cam_right[k];
+        S.cam_up[k] = (float)d->cam_up[k]; S.cam_fwd[k] = (float)d->cam_forward[k];
+    }
+    S.cam_d = (float)d->cam_d; S.dof_strength = (float)d->cam_dof_strength; S.dof_dist = (float)d->cam_dof_dist;
+    S.dof_on = !(d->cam_dof_dist == 0 || d->cam_dof_strength == 0);   // camera.py:41
+    S.sky = has_sky ? c->sky.as<uint32_t>() : nullptr; S.sky_w = has_sky ? d->sky_w : 0; S.sky_h = has_sky ? d->sky_h : 0;
+    S.sky_scale = (float)d->sky_scale;
+    c->has_tri = !rows_live.empty(); c->has_sph = d->n_spheres > 0; c->det_cut = any_det;
+    c->has_scene = true;
+    return RT_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// closest-hit entry
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct IsectArgs {
+    long long n;
+    const double *org, *dir; const int32_t *origin;
+    int32_t *obj, *prim, *gprim, *how; double *t, *normal, *pos;
+    unsigned long long *stats;
+};
+
+template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
+__global__ __launch_bounds__(256) void k_intersect(const DevScene S, const IsectArgs A) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const double ox = A.org[3 * i], oy = A.org[3 * i + 1], oz = A.org[3 * i + 2];
+    const double dx = A.dir[3 * i], dy = A.dir[3 * i + 1], dz = A.dir[3 * i + 2];
+    const int32_t origin = A.origin ? A.origin[i] : -1;
+    const float fox = (float)ox, foy = (float)oy, foz = (float)oz, fdx = (float)dx, fdy = (float)dy, fdz = (float)dz;
+    // The float32 filter is only valid for the ray it is given: rays that are not exactly
+    // representable in float32 are answered by the exact code on the doubles themselves.
+    const bool f32_ray = (double)fox == ox && (double)foy == oy && (double)foz == oz && (double)fdx == dx &&
+                         (double)fdy == dy && (double)fdz == dz;
+    SceneHit e; e.obj = -2;
+    Hit h; h.obj = -1; h.how = 2;
+    HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
+    if (f32_ray) {
+        Ray r = make_ray(S, fox, foy, foz, fdx, fdy, fdz, origin);
+        h = closest_hit<HAS_TRI, HAS_SPH, DETCUT>(S, r, cnt, &e);
+    } else {
+        e = exact_scan(S, d3(ox, oy, oz), d3(dx, dy, dz), origin);
+        h.obj = e.obj; h.prim = e.prim; h.gprim = e.gprim; h.how = 2; cnt.exact = 1;
+    }
+    const bool have64 = e.obj != -2;
+    A.obj[i] = h.obj; A.prim[i] = h.prim;
+    if (A.gprim) A.gprim[i] = h.gprim;
+    if (A.how) A.how[i] = h.how;
+    const bool hit = h.obj >= 0;
+    A.t[i] = !hit ? (double)INFINITY : (have64 ? e.t : (double)h.t);
+    if (A.normal) {
+        A.normal[3 * i] = !hit ? 0.0 : (have64 ? e.n.x : (double)h.nx);
+        A.normal[3 * i + 1] = !hit ? 0.0 : (have64 ? e.n.y : (double)h.ny);
+        A.normal[3 * i + 2] = !hit ? 0.0 : (have64 ? e.n.z : (double)h.nz);
+    }
+    if (A.pos) {
+        A.pos[3 * i] = !hit ? 0.0 : (have64 ? e.pos.x : (double)h.px);
+        A.pos[3 * i + 1] = !hit ? 0.0 : (have64 ? e.pos.y : (double)h.py);
+        A.pos[3 * i + 2] = !hit ? 0.0 : (have64 ? e.pos.z : (double)h.pz);
+    }
+    if (cnt.exact) atomicAdd(A.stats + kStatExact, (unsigned long long)cnt.exact);
+    if (cnt.refine) atomicAdd(A.stats + kStatRefine, (unsigned long long)cnt.refine);
+}
+
+template <class F> void dispatch_variant(bool tri, bool sph, bool det, F &&f) {
+    if (tri && sph) { if (det) f(std::true_type{}, std::true_type{}, std::true_type{}); else f(std::true_type{}, std::true_type{}, std::false_type{}); }
+    else if (tri) { if (det) f(std::true_type{}, std::false_type{}, std::true_type{}); else f(std::true_type{}, std::false_type{}, std::false_type{}); }
+    else f(std::false_type{}, std::true_type{}, std::false_type{});
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_intersect_batch(rt_ctx *c, int64_t n, const double *org, const double *dir, const int32_t *origin_prim,
+                       int32_t *obj, int32_t *prim, int32_t *gprim, int32_t *how, double *t, double *normal, double *pos) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (n < 0 || (n > 0 && (!org || !dir || !obj || !prim || !t))) return fail(c, RT_ERR_INVALID_ARG, "rt_intersect_batch: bad arguments");
+    if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "rt_intersect_batch: no scene set");
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf b_org, b_dir, b_origin, b_obj, b_prim, b_gprim, b_how, b_t, b_n, b_p;
+    const size_t n3 = 3 * (size_t)n * sizeof(double);
+    HIP_TRY(c, b_org.ensure(n3)); HIP_TRY(c, b_dir.ensure(n3));
+    HIP_TRY(c, hipMemcpy(b_org.p, org, n3, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(b_dir.p, dir, n3, hipMemcpyHostToDevice));
+    if (origin_prim) {
+        HIP_TRY(c, b_origin.ensure(n * sizeof(int32_t)));
+        HIP_TRY(c, hipMemcpy(b_origin.p, origin_prim, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(c, b_obj.ensure(n * 4)); HIP_TRY(c, b_prim.ensure(n * 4)); HIP_TRY(c, b_gprim.ensure(n * 4)); HIP_TRY(c, b_how.ensure(n * 4));
+    HIP_TRY(c, b_t.ensure(n * 8)); HIP_TRY(c, b_n.ensure(n3)); HIP_TRY(c, b_p.ensure(n3));
+    IsectArgs A{};
+    A.n = n; A.org = b_org.as<double>(); A.dir = b_dir.as<double>(); A.origin = origin_prim ? b_origin.as<int32_t>() : nullptr;
+    A.obj = b_obj.as<int32_t>(); A.prim = b_prim.as<int32_t>(); A.gprim = b_gprim.as<int32_t>(); A.how = b_how.as<int32_t>();
+    A.t = b_t.as<double>(); A.normal = b_n.as<double>(); A.pos = b_p.as<double>(); A.stats = c->stats.as<unsigned long long>();
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    const DevScene S = c->S;
+    dispatch_variant(c->has_tri, c->has_sph, c->det_cut, [&](auto T, auto P, auto D) {
+        hipLaunchKernelGGL((k_intersect<decltype(T)::value, decltype(P)::value, decltype(D)::value>), dim3(blocks), dim3(256), 0, 0, S, A);
+    });
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(obj, b_obj.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(prim, b_prim.p, n * 4, hipMemcpyDeviceToHost));
+    if (gprim) HIP_TRY(c, hipMemcpy(gprim, b_gprim.p, n * 4, hipMemcpyDeviceToHost));
+    if (how) HIP_TRY(c, hipMemcpy(how, b_how.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(t, b_t.p, n * 8, hipMemcpyDeviceToHost));
+    if (normal) HIP_TRY(c, hipMemcpy(normal, b_n.p, n3, hipMemcpyDeviceToHost));
+    if (pos) HIP_TRY(c, hipMemcpy(pos, b_p.p, n3, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// accumulation buffer
+// ---------------------------------------------------------------------------------------------
+int rt_accum_resize(rt_ctx *c, int32_t w, int32_t h) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (w <= 0 || h <= 0 || (long long)w * h > (1ll << 28)) return fail(c, RT_ERR_INVALID_ARG, "rt_accum_resize: bad size %d x %d", w, h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, c->accum.ensure((size_t)w * h * 3 * sizeof(float)));
+    c->acc_w = w; c->acc_h = h;
+    HIP_TRY(c, hipMemset(c->accum.p, 0, (size_t)w * h * 3 * sizeof(float)));
+    return RT_OK;
+}
+
+int rt_accum_clear(rt_ctx *c) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (!c->accum.p) return fail(c, RT_ERR_INVALID_ARG, "rt_accum_clear: no buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemset(c->accum.p, 0, (size_t)c->acc_w * c->acc_h * 3 * sizeof(float)));
+    return RT_OK;
+}
+
+void *rt_accum_device_ptr(rt_ctx *c) { return (c && c->acc_w) ? c->accum.p : nullptr; }
+
+int rt_accum_read(rt_ctx *c, float *host) {
+    if (!c || !host) return fail(c, RT_ERR_INVALID_ARG, "rt_accum_read: NULL argument");
+    if (!c->acc_w) return fail(c, RT_ERR_INVALID_ARG, "rt_accum_read: no buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(host, c->accum.p, (size_t)c->acc_w * c->acc_h * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// render
+// ---------------------------------------------------------------------------------------------
+int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stream_) {
+    if (!c || !p) return fail(c, RT_ERR_INVALID_ARG, "rt_render: NULL argument");
+    if (p->struct_size != sizeof(rt_render_params)) return fail(c, RT_ERR_INVALID_ARG, "rt_render_params.struct_size mismatch");
+    if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "rt_render: no scene set");
+    if (c->stop.load()) return fail(c, RT_ERR_STOPPED, "rt_render: stop requested");
+    if (p->width <= 0 || p->height <= 0 || p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x1 < p->x0 || p->y1 < p->y0)
+        return fail(c, RT_ERR_INVALID_ARG, "rt_render: rectangle [%d,%d)x[%d,%d) outside %dx%d", p->x0, p->x1, p->y0, p->y1, p->width, p->height);
+    if (p->sample_count < 0 || p->sample_begin < 0 || p->max_bounces < 0 || p->max_bounces > 62)
+        return fail(c, RT_ERR_INVALID_ARG, "rt_render: bad sample range or max_bounces");
+    float *accum = accum_dev;
+    if (!accum) {
+        if (c->acc_w != p->width || c->acc_h != p->height)
+            return fail(c, RT_ERR_INVALID_ARG, "rt_render: context buffer is %dx%d, call rt_accum_resize(%d,%d) first", c->acc_w, c->acc_h, p->width, p->height);
+        accum = c->accum.as<float>();
+    }
+    const long long rect_px = (long long)(p->x1 - p->x0) * (p->y1 - p->y0);
+    if (rect_px == 0 || p->sample_count == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = (hipStream_t)stream_;
+
+    // Job granularity: enough (pixel, chunk) jobs that every resident lane runs many of them, so the
+    // end-of-launch tail (lanes waiting for the last jobs) stays a few percent of the launch.
+    const long long lanes = (long long)c->n_cu * 2048;
+    long long want_chunks = (48 * lanes + rect_px - 1) / rect_px;
+    int n_chunks = (int)std::min<long long>(std::max<long long>(want_chunks, 1), p->sample_count);
+    int chunk_samples = (p->sample_count + n_chunks - 1) / n_chunks;
+    n_chunks = (p->sample_count + chunk_samples - 1) / chunk_samples;
+    const long long total_jobs = rect_px * n_chunks;
+    if (total_jobs >= (1ll << 32) - 2 * kJobBlock) return fail(c, RT_ERR_INVALID_ARG, "rt_render: too many jobs in one call; split the sample range");
+
+    RenderArgs A{};
+    A.width = p->width; A.height = p->height; A.x0 = p->x0; A.y0 = p->y0; A.rect_w = p->x1 - p->x0; A.rect_h = p->y1 - p->y0;
+    A.sample_begin = p->sample_begin; A.sample_count = p->sample_count; A.chunk_samples = chunk_samples; A.n_chunks = n_chunks;
+    A.max_bounces = p->max_bounces; A.seed_lo = (uint32_t)p->seed; A.seed_hi = (uint32_t)(p->seed >> 32);
+    A.total_jobs = (uint32_t)total_jobs; A.job_counter = c->job_counter.as<uint32_t>(); A.accum = accum;
+    A.stats = c->stats.as<unsigned long long>();
+    if (n_chunks > 1) {
+        // grows only; a larger request first drains work that may still read the old buffer
+        size_t need = (size_t)total_jobs * 3 * sizeof(float);
+        if (need > c->partial.bytes) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, c->partial.ensure(need)); }
+        A.partial = c->partial.as<float>();
+    }
+    HIP_TRY(c, hipMemsetAsync(c->job_counter.p, 0, 256, stream));
+    const long long waves_needed = (total_jobs + 63) / 64;
+    const unsigned blocks = (unsigned)std::min<long long>((waves_needed + 3) / 4, (long long)c->n_cu * 8);
+    EventPair ev;
+    HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b));
+    HIP_TRY(c, hipEventRecord(ev.a, stream));
+    const DevScene S = c->S;
+    dispatch_variant(c->has_tri, c->has_sph, c->det_cut, [&](auto T, auto P, auto D) {
+        hipLaunchKernelGGL((k_render<decltype(T)::value, decltype(P)::value, decltype(D)::value>), dim3(blocks), dim3(256), 0, stream, S, A);
+    });
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(ev.b, stream));
+    if (n_chunks > 1) {
+        hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((rect_px + 255) / 256)), dim3(256), 0, stream, A);
+        HIP_TRY(c, hipGetLastError());
+    }
+    { std::lock_guard<std::mutex> g(c->mu); c->timed.push_back(ev); c->launches++; }
+    return RT_OK;
+}
+
+int rt_synchronize(rt_ctx *c, void *stream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)stream));
+    return RT_OK;
+}
+
+int rt_request_stop(rt_ctx *c) { if (!c) return RT_ERR_INVALID_ARG; c->stop.store(1); return RT_OK; }
+int rt_clear_stop(rt_ctx *c) { if (!c) return RT_ERR_INVALID_ARG; c->stop.store(0); return RT_OK; }
+
+static int drain_events(rt_ctx *c) {
+    std::vector<EventPair> evs;
+    { std::lock_guard<std::mutex> g(c->mu); evs.swap(c->timed); }
+    double ms_sum = 0;
+    for (auto &e : evs) {
+        float ms = 0;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) ms_sum += ms;
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms += ms_sum; }
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx *c, rt_stats *out) {
+    if (!c || !out) return fail(c, RT_ERR_INVALID_ARG, "rt_get_stats: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    drain_events(c);
+    unsigned long long v[kStatCount];
+    HIP_TRY(c, hipMemcpy(v, c->stats.p, sizeof v, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->rays = v[kStatRays]; out->paths = v[kStatPaths]; out->sphere_tests = v[kStatSphTests]; out->tri_tests = v[kStatTriTests];
+    out->aabb_tests = 0; out->bvh_node_tests = v[kStatBvhNodes]; out->exact_rays = v[kStatExact]; out->refined_hits = v[kStatRefine];
+    out->sky_lookups = v[kStatSky]; out->shaded_hits = v[kStatShaded];
+    { std::lock_guard<std::mutex> g(c->mu); out->kernel_ms = c->kernel_ms; out->launches = c->launches; }
+    return RT_OK;
+}
+
+int rt_reset_stats(rt_ctx *c) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    drain_events(c);
+    HIP_TRY(c, hipMemset(c->stats.p, 0, sizeof(unsigned long long) * kStatCount));
+    { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms = 0; c->launches = 0; }
+    return RT_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// RNG known-answer hook
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_debug_uniforms(uint32_t key0, uint32_t key1, int n_segments, float *out) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segments) return;
+    Draws d = segment_draws(key0, key1, (uint32_t)s);
+    out[5 * s] = d.f0; out[5 * s + 1] = d.f1; out[5 * s + 2] = d.f2; out[5 * s + 3] = d.f3; out[5 * s + 4] = d.f4;
+}
+}  // namespace
+
+extern "C" int rt_debug_uniforms(rt_ctx *c, uint32_t pixel, uint32_t sample, uint64_t seed, int32_t n_segments, float *out_host) {
+    if (!c || !out_host || n_segments <= 0) return fail(c, RT_ERR_INVALID_ARG, "rt_debug_uniforms: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf b;
+    HIP_TRY(c, b.ensure((size_t)n_segments * 5 * sizeof(float)));
+    hipLaunchKernelGGL(k_debug_uniforms, dim3((n_segments + 63) / 64), dim3(64), 0, 0, pixel ^ (uint32_t)seed, sample ^ (uint32_t)(seed >> 32), n_segments, b.as<float>());
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(out_host, b.p, (size_t)n_segments * 5 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}

@@ -1,0 +1,144 @@
+// Double-precision "exact" intersection code: the reference semantics of upstream's
+// Sphere.intersect (src/mesh/sphere.py:13-41), Mesh.intersect_aabb / intersect_tri
+// (src/mesh/mesh.py:61-143) and Scene.intersect (src/raytracing/scene.py:23-27), evaluated
+// operation by operation in upstream's order with no fused multiply-add (the translation unit is
+// built with -ffp-contract=off).  It runs only for rays or primitives the float32 filter could
+// not decide, so it is written for clarity, not speed.
+//
+// Ray-origin rule ("origin primitive"): a bounce ray starts on the primitive it just hit.  Upstream
+// relies on `depth > 1e-10` in double precision to drop that self-intersection (scene.py:25);
+// positions here are float32, so the originating primitive is carried with the ray instead:
+// the originating triangle is skipped, and of the originating sphere only the far root counts,
+// and only when the ray heads into the sphere.  origin < 0 means "no such primitive" and gives
+// upstream's semantics unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rt_scene.h"
+
+namespace rt {
+
+#define RT_DEV __device__ __forceinline__
+
+struct D3 { double x, y, z; };
+RT_DEV D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV D3 dsub(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV D3 dcross(D3 a, D3 b) { return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_DEV D3 dat(D3 o, D3 d, double t) { return d3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t); }
+RT_DEV D3 dnormalize(D3 a) { double l = __builtin_sqrt(ddot(a, a)); return d3(a.x / l, a.y / l, a.z / l); }
+
+struct ExactHit {
+    bool hit;
+    int32_t prim;   // sphere: 0 near root, 1 far root; triangle: unused
+    double t;
+    D3 n, pos;
+};
+
+// Sphere.intersect restricted to its first hit that survives Scene.intersect's depth filter.
+RT_DEV ExactHit exact_sphere(const double *sp, D3 o, D3 d, bool is_origin) {
+    ExactHit h; h.hit = false; h.prim = 0; h.t = 0; h.n = d3(0, 0, 0); h.pos = h.n;
+    D3 c = d3(sp[0], sp[1], sp[2]);
+    double radius = sp[3];
+    D3 ro = dsub(o, c);
+    double a = ddot(d, d);
+    double b = 2 * ddot(ro, d);
+    double cc = ddot(ro, ro) - radius * radius;
+    double rad = b * b - 4 * a * cc;
+    if (!(rad >= 0)) return h;
+    double sq = __builtin_sqrt(rad);
+    double t1 = (-b - sq) / (2 * a), t2 = (-b + sq) / (2 * a);
+    double t; int root;
+    if (!is_origin) {
+        if (t1 > 1e-10) { t = t1; root = 0; }
+        else if (t2 > 1e-10) { t = t2; root = 1; }
+        else return h;
+    } else {
+        if (b < 0 && t2 > 1e-10) { t = t2; root = 1; }
+        else return h;
+    }
+    h.hit = true; h.prim = root; h.t = t;
+    h.pos = dat(o, d, t);
+    h.n = dnormalize(dsub(h.pos, c));
+    return h;
+}
+
+// Mesh.intersect_aabb
+RT_DEV bool exact_aabb(const double *bb, D3 o, D3 d) {
+    double ix = d.x != 0 ? 1 / d.x : 1e10, iy = d.y != 0 ? 1 / d.y : 1e10, iz = d.z != 0 ? 1 / d.z : 1e10;
+    double ax = (bb[0] - o.x) * ix, ay = (bb[1] - o.y) * iy, az = (bb[2] - o.z) * iz;
+    double bx = (bb[3] - o.x) * ix, by = (bb[4] - o.y) * iy, bz = (bb[5] - o.z) * iz;
+    double lx = bx < ax ? bx : ax, ly = by < ay ? by : ay, lz = bz < az ? bz : az;
+    double hx = bx > ax ? bx : ax, hy = by > ay ? by : ay, hz = bz > az ? bz : az;
+    double tn = lx; if (ly > tn) tn = ly; if (lz > tn) tn = lz;
+    double tf = hx; if (hy < tf) tf = hy; if (hz < tf) tf = hz;
+    double lo = tn; if (0 > lo) lo = 0;
+    return tf >= lo;
+}
+
+// Mesh.intersect_tri + the depth filter
+RT_DEV ExactHit exact_tri(const double *tv, D3 o, D3 d) {
+    ExactHit h; h.hit = false; h.prim = 0; h.t = 0; h.n = d3(0, 0, 0); h.pos = h.n;
+    D3 pa = d3(tv[0], tv[1], tv[2]), pb = d3(tv[3], tv[4], tv[5]), pc = d3(tv[6], tv[7], tv[8]);
+    D3 ab = dsub(pb, pa), ac = dsub(pc, pa);
+    D3 nrm = dcross(ab, ac);
+    double det = -ddot(d, nrm);
+    if (__builtin_fabs(det) < 1e-6) return h;
+    double inv_det = 1 / det;
+    D3 ao = dsub(o, pa);
+    D3 dao = dcross(ao, d);
+    double dst = ddot(nrm, ao) * inv_det;
+    double u = ddot(ac, dao) * inv_det;
+    double v = -ddot(ab, dao) * inv_det;
+    double w = 1 - u - v;
+    if (dst >= 0 && u >= 0 && v >= 0 && w >= 0 && dst > 1e-10) {
+        h.hit = true; h.t = dst; h.pos = dat(o, d, dst); h.n = dnormalize(nrm);
+    }
+    return h;
+}
+
+struct SceneHit {
+    int32_t obj;     // -1 = miss
+    int32_t prim;    // face index / sphere root
+    int32_t gprim;   // sphere index, or n_spheres + triangle index
+    double t;
+    D3 n, pos;
+};
+
+// One primitive by global id, with its mesh's bounding-box gate.
+RT_DEV ExactHit exact_single(const DevScene &S, int32_t gprim, D3 o, D3 d, int32_t origin) {
+    if (gprim < S.n_spheres) return exact_sphere(S.sph64 + 4 * (size_t)gprim, o, d, gprim == origin);
+    int32_t ti = gprim - S.n_spheres;
+    ExactHit miss; miss.hit = false; miss.prim = 0; miss.t = 0; miss.n = d3(0, 0, 0); miss.pos = miss.n;
+    if (gprim == origin) return miss;
+    if (!exact_aabb(S.aabb64 + 6 * (size_t)S.tri_aux[ti].mesh, o, d)) return miss;
+    return exact_tri(S.tri64 + 9 * (size_t)ti, o, d);
+}
+
+// Scene.intersect(ray)[0]: first minimum of depth in object order, then per-object hit order.
+RT_DEV SceneHit exact_scan(const DevScene &S, D3 o, D3 d, int32_t origin) {
+    SceneHit best; best.obj = -1; best.prim = -1; best.gprim = -1; best.t = __builtin_inf();
+    best.n = d3(0, 0, 0); best.pos = best.n;
+    for (int oi = 0; oi < S.n_objects; ++oi) {
+        int idx = S.obj_index[oi];
+        if (S.obj_kind[oi] == 0) {
+            ExactHit h = exact_sphere(S.sph64 + 4 * (size_t)idx, o, d, idx == origin);
+            if (h.hit && h.t < best.t) {
+                best.obj = oi; best.prim = h.prim; best.gprim = idx; best.t = h.t; best.n = h.n; best.pos = h.pos;
+            }
+        } else {
+            if (!exact_aabb(S.aabb64 + 6 * (size_t)idx, o, d)) continue;
+            int t0 = S.mesh_tri_begin[idx], t1 = S.mesh_tri_begin[idx + 1];
+            for (int ti = t0; ti < t1; ++ti) {
+                if (S.n_spheres + ti == origin) continue;
+                ExactHit h = exact_tri(S.tri64 + 9 * (size_t)ti, o, d);
+                if (h.hit && h.t < best.t) {
+                    best.obj = oi; best.prim = ti - t0; best.gprim = S.n_spheres + ti; best.t = h.t;
+                    best.n = h.n; best.pos = h.pos;
+                }
+            }
+        }
+    }
+    return best;
+}
+
+}  // namespace rt

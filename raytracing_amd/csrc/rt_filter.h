@@ -1,0 +1,354 @@
+// float32 closest-hit search with conservative error bounds ("filter"), and the logic that turns
+// its answer into a hit that equals upstream's Scene.intersect(ray)[0].
+//
+// Contract of the filter: a primitive that upstream's double-precision arithmetic would report
+// as hit is ALWAYS a candidate here, and every candidate carries a lower bound t_lo <= its true
+// depth.  Candidates are ordered by a 32-bit key = (bits of t_lo with the low bits cleared) | id;
+// positive floats order like their bit patterns, so one v_min_u32 keeps the best candidate and
+// one v_med3_u32 the runner-up.  After the loops the winner is re-evaluated with per-lane loads:
+//   * certainly hit, certainly alone in front, precise enough  -> accepted as is (float32);
+//   * anything else -> that primitive (or, for a possible tie / a rejected winner, the whole
+//     scene) is re-evaluated by the double-precision code in rt_exact.h.
+// So hit identity never depends on float32 rounding; float32 only decides how often the slow
+// path runs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rt_exact.h"
+#include "rt_scene.h"
+
+namespace rt {
+
+RT_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+RT_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+RT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RT_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_DEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+RT_DEV float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
+RT_DEV float min_(float a, float b) { return __builtin_fminf(a, b); }
+RT_DEV float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+RT_DEV float abs_(float a) { return __builtin_fabsf(a); }
+RT_DEV uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+RT_DEV uint32_t umed3_(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Wave-uniform table reads.  A load through a constant-address-space pointer at a wave-uniform
+// address is issued on the scalar unit (s_load_dwordx4/x8/x16): the row lands in SGPRs and feeds
+// the VALU as a scalar operand, costing no vector instruction and no VGPR.  (Through an ordinary
+// global pointer the compiler cannot prove the tables are not written by this kernel's own stores
+// and falls back to per-lane vector loads.)
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const f4 __attribute__((address_space(4))) *const_f4_ptr;
+RT_DEV const_f4_ptr as_const_f4(const void *p) { return (const_f4_ptr)(const f4 *)p; }
+
+RT_DEV TriRow load_tri_row_uniform(const TriRow *rows, int i) {
+    const_f4_ptr q = as_const_f4(rows) + 4 * (size_t)i;
+    f4 a = q[0], b = q[1], c = q[2], d = q[3];
+    TriRow T;
+    T.nx = a.x; T.ny = a.y; T.nz = a.z; T.kn = a.w;
+    T.e1x = b.x; T.e1y = b.y; T.e1z = b.z; T.k1 = b.w;
+    T.e2x = c.x; T.e2y = c.y; T.e2z = c.z; T.k2 = c.w;
+    T.cb = d.x; T.ct = d.y; T.det_lo = d.z;
+    const float id_bits = d.w;   // copy out first: bit-casting a vector element expression reads lane 0
+    T.gprim = (int32_t)f2u(id_bits);
+    return T;
+}
+
+RT_DEV SphRow load_sph_row_uniform(const SphRow *rows, int i) {
+    const_f4_ptr q = as_const_f4(rows) + 2 * (size_t)i;
+    f4 a = q[0], b = q[1];
+    SphRow P;
+    P.cx = a.x; P.cy = a.y; P.cz = a.z; P.r2 = a.w;
+    P.qs = b.x; P.cn = b.y; P.r = b.z;
+    const float id_bits = b.w;
+    P.gprim = (int32_t)f2u(id_bits);
+    return P;
+}
+
+constexpr uint32_t kKeyNone = 0x7F800000u;   // keys at or above +inf's pattern mean "no candidate"
+constexpr float kInf = __builtin_inff();
+constexpr float kBandM2 = 54.0f * kU;        // discriminant bound, |ro|^2 coefficient (2x the derived 27u)
+constexpr float kTCertain = 1e-9f;           // a depth bound above this certainly passes upstream's 1e-10 filter
+
+// A ray prepared for the filter.  All bounds assume 1/2 <= |d| <= 2 and no exactly-zero component
+// of d (such rays go straight to the exact code: see ray_needs_exact).
+struct Ray {
+    float ox, oy, oz, dx, dy, dz;
+    float a, inv_a, dlen;  // d.d, 1/(d.d), |d|
+    float cr;              // 2 u S D : S = |o|_1 + scene_radius, D = max(|d|, 1/|d|)
+    float band0;           // crude per-ray discriminant bound for the in-loop sphere test
+    int32_t origin;        // global id of the primitive the ray starts on, -1 = none
+};
+
+RT_DEV Ray make_ray(const DevScene &S, float ox, float oy, float oz, float dx, float dy, float dz, int32_t origin) {
+    Ray r;
+    r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
+    r.a = fma_(dz, dz, fma_(dy, dy, dx * dx));
+    r.inv_a = rcp_(r.a);
+    r.dlen = sqrt_(r.a);
+    float D = max_(r.dlen, rsq_(r.a)) * 1.0001f;
+    float Sr = abs_(ox) + abs_(oy) + abs_(oz) + S.scene_radius;
+    r.cr = 2.0f * kU * Sr * D;
+    r.band0 = 72.0f * kU * r.a * Sr * Sr;
+    r.origin = origin;
+    return r;
+}
+
+RT_DEV bool ray_needs_exact(const Ray &r) {
+    bool ok = (r.a >= 0.25f) && (r.a <= 4.0f) && (r.dx != 0.0f) && (r.dy != 0.0f) && (r.dz != 0.0f);
+    float s = abs_(r.ox) + abs_(r.oy) + abs_(r.oz);
+    return !(ok && s < 1e30f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangles
+// ---------------------------------------------------------------------------------------------
+struct TriEval { float m, t, g, nd; };
+
+// 21 VALU instructions: the arithmetic of mesh.py:122-133 restated at the hit point.
+RT_DEV TriEval tri_eval(const TriRow &T, const Ray &r) {
+    TriEval e;
+    e.nd = fma_(T.nz, r.dz, fma_(T.ny, r.dy, T.nx * r.dx));
+    float no = fma_(T.nz, r.oz, fma_(T.ny, r.oy, fma_(T.nx, r.ox, T.kn)));
+    float inv = rcp_(e.nd);
+    e.t = -no * inv;
+    float px = fma_(e.t, r.dx, r.ox), py = fma_(e.t, r.dy, r.oy), pz = fma_(e.t, r.dz, r.oz);
+    float u = fma_(T.e1z, pz, fma_(T.e1y, py, fma_(T.e1x, px, T.k1)));
+    float v = fma_(T.e2z, pz, fma_(T.e2y, py, fma_(T.e2x, px, T.k2)));
+    float w = (1.0f - u) - v;
+    e.m = min_(min_(u, v), w);
+    e.g = r.cr * abs_(inv);
+    return e;
+}
+
+struct Best { uint32_t k0, k1; };  // best and runner-up keys
+
+RT_DEV void best_insert(Best &b, uint32_t key) {
+    b.k1 = umed3_(b.k0, b.k1, key);
+    b.k0 = umin_(b.k0, key);
+}
+
+template <bool DETCUT>
+RT_DEV void search_tris(const DevScene &S, const Ray &r, Best &b, uint32_t keep_mask) {
+    const int n = S.n_tri_rows;
+    const TriRow *rows = S.tri_rows;
+#pragma unroll 2
+    for (int i = 0; i < n; ++i) {
+        const TriRow T = load_tri_row_uniform(rows, i);
+        TriEval e = tri_eval(T, r);
+        float mp = fma_(e.g, T.cb, e.m);
+        float thi = fma_(e.g, T.ct, e.t);
+        float tlo = fma_(-e.g, T.ct, e.t);
+        float x = min_(mp, thi);
+        float y = x * (-kInf);                 // x < 0 -> +inf (not a candidate); x >= 0 -> -inf / NaN
+        float tl = max_(max_(tlo, 0.0f), y);   // NaNs drop out of max: a NaN anywhere keeps the candidate
+        uint32_t key = (f2u(tl) & keep_mask) | (uint32_t)T.gprim;
+        bool kill = (T.gprim == r.origin);
+        if (DETCUT) kill = kill || !(abs_(e.nd) >= T.det_lo);
+        key = kill ? 0xFFFFFFFFu : key;
+        best_insert(b, key);
+    }
+}
+
+// Winner re-evaluation.  status: 0 accept float32 result, 1 identity certain but imprecise,
+// 2 undecided (ask the exact code about this primitive).
+struct Verdict { int status; float t, thi; };
+
+RT_DEV Verdict judge_tri(const DevScene &S, int32_t ti, const Ray &r) {
+    const TriRow T = S.tri_by_id[ti];
+    TriEval e = tri_eval(T, r);
+    float bb = e.g * T.cb, bt = e.g * T.ct;
+    bool certain = (e.m - bb >= 0.0f) && (e.t - bt > kTCertain) && (abs_(e.nd) >= S.tri_aux[ti].det_hi);
+    Verdict v;
+    v.t = e.t; v.thi = e.t + bt;
+    v.status = !certain ? 2 : ((bt <= 2e-6f * e.t) ? 0 : 1);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small spheres
+// ---------------------------------------------------------------------------------------------
+struct SphBounds { float t1lo, t1hi, t2lo, t2hi, b, eb; bool maybe, surely; float t1, t2; };
+
+// Bounds on both roots from the cancellation-free form (t - tc)^2 = (r^2 - |ro + tc d|^2) / a.
+RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
+    SphBounds o;
+    float rox = r.ox - P.cx, roy = r.oy - P.cy, roz = r.oz - P.cz;
+    float b = fma_(roz, r.dz, fma_(roy, r.dy, rox * r.dx));
+    float m2 = fma_(roz, roz, fma_(roy, roy, rox * rox));
+    float mlen = sqrt_(m2);
+    float tc = -b * r.inv_a;
+    float lx = fma_(tc, r.dx, rox), ly = fma_(tc, r.dy, roy), lz = fma_(tc, r.dz, roz);
+    float l2 = fma_(lz, lz, fma_(ly, ly, lx * lx));
+    float h2 = P.r2 - l2;
+    // per-component error of l: rounding of ro (u|ro|), of the centre (u|c|), of tc*d (~4u|ro|)
+    float dl = kU * (8.0f * mlen + 2.0f * P.cn);
+    float dh2 = 4.0f * sqrt_(l2) * dl + 3.0f * dl * dl + 8.0f * kU * (l2 + P.r2);
+    float hhi = h2 + dh2, hlo = h2 - dh2;
+    o.maybe = hhi >= 0.0f;
+    o.surely = hlo > 0.0f;
+    float shi = sqrt_(max_(hhi, 0.0f) * r.inv_a) * (1.0f + 8.0f * kU);
+    float slo = sqrt_(max_(hlo, 0.0f) * r.inv_a) * (1.0f - 8.0f * kU);
+    float smid = sqrt_(max_(h2, 0.0f) * r.inv_a);
+    // error of tc: b has abs error <= u|d|(5|ro| + 2|c|), a and 1/a rel error <= 6u
+    float eb = 2.0f * kU * r.dlen * (5.0f * mlen + 2.0f * P.cn) * r.inv_a + 8.0f * kU * abs_(tc);
+    o.t1lo = tc - shi - eb; o.t1hi = tc - slo + eb;
+    o.t2lo = tc + slo - eb; o.t2hi = tc + shi + eb;
+    o.t1 = tc - smid; o.t2 = tc + smid;
+    o.b = b; o.eb = 2.0f * kU * r.dlen * (5.0f * mlen + 2.0f * P.cn);
+    return o;
+}
+
+RT_DEV void search_spheres(const DevScene &S, const Ray &r, Best &bst, uint32_t keep_mask) {
+    const int n = S.n_sph_rows;
+    const SphRow *rows = S.sph_rows;
+#pragma unroll 2
+    for (int i = 0; i < n; ++i) {
+        const SphRow P = load_sph_row_uniform(rows, i);
+        float rox = r.ox - P.cx, roy = r.oy - P.cy, roz = r.oz - P.cz;
+        float b = fma_(roz, r.dz, fma_(roy, r.dy, rox * r.dx));
+        float cq = fma_(roz, roz, fma_(roy, roy, fma_(rox, rox, -P.r2)));
+        float disc = fma_(b, b, -(r.a * cq));
+        if (disc >= -r.band0) {  // rare per lane: the precise bounds are worked out in here
+            SphBounds o = sphere_bounds(P, r);
+            bool valid; float tl;
+            if (P.gprim == r.origin) {           // only the far root, only when heading inwards
+                valid = o.maybe && (o.b < o.eb);
+                tl = max_(o.t2lo, 0.0f);
+            } else {
+                valid = o.maybe && (o.t2hi > 0.0f);
+                tl = (o.t1hi > 0.0f) ? max_(o.t1lo, 0.0f) : max_(o.t2lo, 0.0f);
+            }
+            uint32_t key = valid ? ((f2u(tl) & keep_mask) | (uint32_t)P.gprim) : 0xFFFFFFFFu;
+            best_insert(bst, key);
+        }
+    }
+}
+
+struct SphVerdict { int status; int root; float t, thi; };
+
+RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r) {
+    const SphRow P = S.sph_by_id[si];
+    SphBounds o = sphere_bounds(P, r);
+    SphVerdict v; v.status = 2; v.root = 0; v.t = 0; v.thi = 0;
+    float lo, hi, t; int root; bool certain;
+    if (si == r.origin) {
+        certain = o.surely && (o.b < -o.eb) && (o.t2lo > kTCertain);
+        lo = o.t2lo; hi = o.t2hi; t = o.t2; root = 1;
+    } else if (o.t1lo > kTCertain) {
+        certain = o.surely; lo = o.t1lo; hi = o.t1hi; t = o.t1; root = 0;
+    } else {
+        certain = o.surely && (o.t1hi < 0.0f) && (o.t2lo > kTCertain);
+        lo = o.t2lo; hi = o.t2hi; t = o.t2; root = 1;
+    }
+    if (!certain) return v;
+    v.root = root; v.t = t; v.thi = hi;
+    // precise enough?  depth to 2e-6 relative, and the normal (pos - c)/r to ~3e-6
+    float perr = 0.5f * (hi - lo) * r.dlen + 4.0f * kU * (abs_(r.ox) + abs_(r.oy) + abs_(r.oz) + P.cn + t * r.dlen);
+    bool precise = (0.5f * (hi - lo) <= 2e-6f * t) && (perr <= 3e-6f * P.r);
+    v.status = precise ? 0 : 1;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Closest hit
+// ---------------------------------------------------------------------------------------------
+struct Hit {
+    int32_t obj, prim, gprim;   // obj < 0: miss
+    float t, nx, ny, nz, px, py, pz;
+    int32_t how;                // 0 float32 fast path, 1 refined in double, 2 exact scene scan
+};
+
+struct HitCounters { uint32_t exact, refine; };
+
+RT_DEV void hit_from_exact_scan(const DevScene &S, D3 o, D3 d, int32_t origin, Hit &h, SceneHit *keep) {
+    SceneHit e = exact_scan(S, o, d, origin);
+    if (keep) *keep = e;
+    h.how = 2; h.obj = e.obj; h.prim = e.prim; h.gprim = e.gprim;
+    h.t = (float)e.t; h.nx = (float)e.n.x; h.ny = (float)e.n.y; h.nz = (float)e.n.z;
+    h.px = (float)e.pos.x; h.py = (float)e.pos.y; h.pz = (float)e.pos.z;
+}
+
+// `keep`, when given, receives the double-precision record whenever the exact code produced the hit.
+template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
+RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, SceneHit *keep) {
+    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
+    const D3 o64 = d3(r.ox, r.oy, r.oz), d64 = d3(r.dx, r.dy, r.dz);
+    if (keep) keep->obj = -2;
+    if (ray_needs_exact(r)) {
+        cnt.exact++;
+        hit_from_exact_scan(S, o64, d64, r.origin, h, keep);
+        return h;
+    }
+    const uint32_t keep_mask = ~S.key_mask;
+    Best b; b.k0 = 0xFFFFFFFFu; b.k1 = 0xFFFFFFFFu;
+    if (HAS_SPH) {
+        search_spheres(S, r, b, keep_mask);
+        for (int i = 0; i < S.n_big_sph; ++i) {   // the few huge spheres: double precision throughout
+            int si = S.big_sph[i];
+            ExactHit e = exact_sphere(S.sph64 + 4 * (size_t)si, o64, d64, si == r.origin);
+            float tl = (float)e.t * (1.0f - 4.0f * kU);
+            uint32_t key = e.hit ? ((f2u(tl) & keep_mask) | (uint32_t)si) : 0xFFFFFFFFu;
+            best_insert(b, key);
+        }
+    }
+    if (HAS_TRI) search_tris<DETCUT>(S, r, b, keep_mask);
+    if (b.k0 >= kKeyNone) return h;   // nothing can be hit: the filter is conservative
+
+    const int32_t gprim = (int32_t)(b.k0 & S.key_mask);
+    const float second_lo = u2f(b.k1 & keep_mask);   // +inf / NaN pattern when there is no runner-up
+    const bool has_second = b.k1 < kKeyNone;
+    int status; float t, thi; int root = 0;
+    if (gprim < S.n_spheres) {
+        SphVerdict v = judge_sphere(S, gprim, r);
+        status = v.status; t = v.t; thi = v.thi; root = v.root;
+    } else {
+        Verdict v = judge_tri(S, gprim - S.n_spheres, r);
+        status = v.status; t = v.t; thi = v.thi;
+    }
+    bool scan = false;
+    ExactHit e; e.hit = false;
+    if (status != 0) {   // undecided or imprecise: double precision for this one primitive
+        cnt.refine++;
+        e = exact_single(S, gprim, o64, d64, r.origin);
+        if (!e.hit) scan = true;            // the winner was not a hit after all
+        else { t = (float)e.t; thi = t * (1.0f + 2.0f * kU); root = e.prim; }
+    }
+    if (!scan && has_second && !(second_lo > thi)) scan = true;   // someone else may be in front, or tie
+    if (scan) {
+        cnt.exact++;
+        hit_from_exact_scan(S, o64, d64, r.origin, h, keep);
+        return h;
+    }
+    h.gprim = gprim;
+    if (gprim < S.n_spheres) {
+        h.obj = S.sph_obj[gprim]; h.prim = root;
+    } else {
+        const TriAux A = S.tri_aux[gprim - S.n_spheres];
+        h.obj = A.obj; h.prim = A.face;
+    }
+    if (e.hit) {
+        h.how = 1;
+        h.t = (float)e.t; h.nx = (float)e.n.x; h.ny = (float)e.n.y; h.nz = (float)e.n.z;
+        h.px = (float)e.pos.x; h.py = (float)e.pos.y; h.pz = (float)e.pos.z;
+        if (keep) { keep->obj = h.obj; keep->prim = h.prim; keep->gprim = gprim; keep->t = e.t; keep->n = e.n; keep->pos = e.pos; }
+        return h;
+    }
+    h.t = t;
+    h.px = fma_(t, r.dx, r.ox); h.py = fma_(t, r.dy, r.oy); h.pz = fma_(t, r.dz, r.oz);
+    if (gprim < S.n_spheres) {
+        const SphRow P = S.sph_by_id[gprim];
+        float ir = rcp_(P.r);
+        float nx = (h.px - P.cx) * ir, ny = (h.py - P.cy) * ir, nz = (h.pz - P.cz) * ir;
+        float s = rsq_(fma_(nz, nz, fma_(ny, ny, nx * nx)));
+        h.nx = nx * s; h.ny = ny * s; h.nz = nz * s;
+    } else {
+        const TriAux A = S.tri_aux[gprim - S.n_spheres];
+        h.nx = A.nx; h.ny = A.ny; h.nz = A.nz;
+    }
+    return h;
+}
+
+}  // namespace rt

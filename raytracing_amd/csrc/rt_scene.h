@@ -1,0 +1,103 @@
+// Device-side scene tables (plain structs shared by the host table builder and the kernels).
+//
+// Two copies of the geometry live in HBM:
+//   * float32 "filter" rows, read with wave-uniform (scalar) loads inside the brute-force loops;
+//     every row carries conservative error-bound constants so that the float32 test can never
+//     reject a primitive the double-precision arithmetic of the upstream code would accept;
+//   * the float64 tables exactly as the host objects hold them, read only by the exact code that
+//     resolves whatever the float32 filter could not decide.
+#pragma once
+#include <stdint.h>
+
+namespace rt {
+
+constexpr float kU = 5.9604644775390625e-08f;  // 2^-24, unit roundoff of binary32
+
+// One live triangle, 16 dwords = one s_load_dwordx16.
+// t = -(N.o + kN) / (N.d);  p = o + t d;  u = e1.p + k1;  v = e2.p + k2;  w = 1 - u - v
+// (u, v are upstream's barycentrics of mesh.py:131-133 expressed at the hit point).
+struct TriRow {
+    float nx, ny, nz, kn;
+    float e1x, e1y, e1z, k1;
+    float e2x, e2y, e2z, k2;
+    float cb;       // barycentric error bound = g * cb,  g = cr * |1/(N.d)|
+    float ct;       // t error bound           = g * ct
+    float det_lo;   // |N.d| below this can never pass upstream's |det| >= 1e-6 cut (mesh.py:123)
+    int32_t gprim;  // global primitive id = n_spheres + triangle index
+};
+
+// Data needed once a triangle has won: unit normal (mesh.py:140), owner, certain-accept cut.
+struct TriAux {
+    float nx, ny, nz;   // normalize(ab x ac), rounded from double
+    float det_hi;       // |N.d| at or above this certainly passes the 1e-6 cut
+    int32_t obj;        // index into scene.objects
+    int32_t face;       // face index inside its mesh
+    int32_t mesh;       // mesh index (for the bounding-box gate of the exact code)
+    int32_t pad;
+};
+
+// One small sphere, 8 dwords = one s_load_dwordx8.
+struct SphRow {
+    float cx, cy, cz, r2;
+    float qs;        // discriminant error bound = a * (kBandM2 * |ro|^2 + qs)
+    float cn;        // |c|, for the bound on ro.d
+    float r;
+    int32_t gprim;   // = sphere index
+};
+
+struct MatRow {      // 8 dwords per object
+    float r, g, b, emission, smoothness, transmittance, ior, r0;  // r0 = ((1-ior)/(1+ior))^2
+};
+
+struct BvhNode {     // mirrors rt_bvh_node
+    float lo[3]; int32_t skip;
+    float hi[3]; int32_t tri_begin_count;
+};
+
+struct DevScene {
+    // float32 filter tables
+    const TriRow *tri_rows;   int32_t n_tri_rows;     // live triangles only
+    const SphRow *sph_rows;   int32_t n_sph_rows;     // small spheres only
+    const int32_t *big_sph;   int32_t n_big_sph;      // sphere indices evaluated in float64
+    const TriRow *tri_by_id;                          // [n_tris] same rows, indexed by triangle id
+    const TriAux *tri_aux;                            // [n_tris]
+    const SphRow *sph_by_id;                          // [n_spheres]
+    const int32_t *sph_obj;                           // [n_spheres]
+    const MatRow *materials;                          // [n_objects]
+    // float64 tables (exact code)
+    const double *tri64;      // [n_tris][9]
+    const double *sph64;      // [n_spheres][4]
+    const double *aabb64;     // [n_meshes][6]
+    const int32_t *mesh_tri_begin;  // [n_meshes+1]
+    const int32_t *obj_kind, *obj_index;
+    int32_t n_objects, n_spheres, n_tris, n_meshes;
+    // BVH (optional)
+    const BvhNode *bvh; int32_t n_bvh; const int32_t *bvh_tri;
+    // scalars
+    float scene_radius;       // bound on |x|+|y|+|z| of every vertex / small-sphere extent
+    uint32_t key_mask;        // low bits of a hit key that hold the primitive id
+    int32_t any_det_cut;      // some live triangle has det_lo > 0
+    // camera (camera.py:17-37)
+    float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
+    float cam_d, dof_strength, dof_dist;
+    int32_t dof_on;
+    // environment: RGBA8 texels, row-major
+    const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale;
+};
+
+struct RenderArgs {
+    int32_t width, height, x0, y0, rect_w, rect_h;
+    int32_t sample_begin, sample_count, chunk_samples, n_chunks;
+    int32_t max_bounces;
+    uint32_t seed_lo, seed_hi;
+    uint32_t total_jobs;
+    uint32_t *job_counter;    // device word, zero at launch
+    float *accum;             // (W,H,3) running sum
+    float *partial;           // [n_chunks][rect_w*rect_h][3] when n_chunks > 1, else unused
+    unsigned long long *stats;  // kStat* counters
+};
+
+enum { kStatRays = 0, kStatPaths, kStatSphTests, kStatTriTests, kStatExact, kStatRefine, kStatSky, kStatShaded,
+       kStatBvhNodes, kStatCount };
+
+}  // namespace rt

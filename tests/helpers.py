@@ -39,7 +39,7 @@ def oracle():
         subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle")])
     lib = C.CDLL(ORACLE_SO)
     lib.orc_uniform.restype = C.c_double
-    lib.orc_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+    lib.orc_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
     lib.orc_schlick.restype = C.c_double
     lib.orc_schlick.argtypes = [_dp, _dp, C.c_double]
     lib.orc_refract.argtypes = [_dp, _dp, C.c_double, _dp]

@@ -12,7 +12,7 @@ Same-sample-sequence trick: upstream draws from ``random.random`` (camera.py:46-
 ``np.random.random`` (renderer.py:62,64; vec3.py:14-16), looked up as module attributes at call
 time.  Before each path both are replaced by one stream that returns Philox4x32-10 uniforms keyed by
 (pixel, sample, seed) in sequential draw order — the very sequence the oracle and the HIP kernels
-generate internally.
+generate internally (one Philox block per path segment, see PathStream).
 
 usage:  python tools/gen_golden.py {kat,scenes,rays,room_image,spheres_image,all} [--procs N]
 """
@@ -57,22 +57,31 @@ def philox4x32_10(ctr, key):
 
 
 class PathStream:
-    """Callable returning the k-th uniform of path (pixel, sample) on the k-th call."""
+    """Callable returning the draws of path (pixel, sample) in call order.
+
+    Segment c of the path owns one Philox block = five 24-bit uniforms; segment 0 is the camera,
+    segment j+1 the shading step after the j-th ``Scene.intersect`` call.  The harness calls
+    ``begin_segment`` from its ``Scene.intersect`` hook, so upstream's own control flow decides
+    which draws are consumed.
+    """
 
     def __init__(self, pixel: int, sample: int, seed: int):
         self.key = ((pixel ^ (seed & _MASK)) & _MASK, (sample ^ (seed >> 32)) & _MASK)
-        self.k = 0
-        self._blk = -1
-        self._words = None
+        self.k = 0          # total draws consumed
+        self.fields = None
+        self.i = 0
+        self.begin_segment(0)
+
+    def begin_segment(self, c: int):
+        x, y, z, w = philox4x32_10((c, 0, 0, 0), self.key)
+        self.fields = (x >> 8, ((x & 0xFF) << 16) | (y >> 16), ((y & 0xFFFF) << 8) | (z >> 24), z & 0xFFFFFF, w >> 8)
+        self.i = 0
 
     def __call__(self, *a, **kw):
-        k = self.k
-        self.k = k + 1
-        b = k >> 2
-        if b != self._blk:
-            self._words = philox4x32_10((b, 0, 0, 0), self.key)
-            self._blk = b
-        return float(self._words[k & 3] >> 8) * (1.0 / 16777216.0)
+        f = self.fields[self.i]   # IndexError here = upstream drew more than five numbers in a segment
+        self.i += 1
+        self.k += 1
+        return float(f) * (1.0 / 16777216.0)
 
 
 _NP_RANDOM_ORIG = np.random.random
@@ -141,12 +150,13 @@ def hit_identity(scene, ray, hit):
     raise AssertionError("hit not reproduced")
 
 
-def trace_recorded(renderer, scene, ray, records):
+def trace_recorded(renderer, scene, ray, records, stream):
     """Run upstream's raytrace while recording every Scene.intersect call it makes."""
     orig = scene.intersect
 
     def spy(r):
         hits = orig(r)
+        stream.begin_segment(len(records) + 1)
         rec = {"o": tuple(r.origin), "d": tuple(r.direction), "inside": bool(r.inside), "n_hits": len(hits)}
         if hits:
             h = hits[0]
@@ -162,6 +172,25 @@ def trace_recorded(renderer, scene, ray, records):
         from src.core import Vec3
 
         return renderer.raytrace(ray, incoming_light=Vec3(0), ray_color=Vec3(1))
+    finally:
+        scene.intersect = orig
+
+
+def trace_hooked(renderer, scene, ray, stream):
+    """Upstream raytrace with the per-segment stream hook: segment j+1 starts when the j-th
+    Scene.intersect call returns."""
+    orig = scene.intersect
+    n = [0]
+
+    def hook(r):
+        hits = orig(r)
+        n[0] += 1
+        stream.begin_segment(n[0])
+        return hits
+
+    scene.intersect = hook
+    try:
+        return renderer.raytrace(ray)
     finally:
         scene.intersect = orig
 
@@ -187,12 +216,12 @@ def render_paths(which, W, H, spp, bounces, xs, record_rays=False, seed=SEED_REN
                     ray = scene.camera.get_ray(u, v)
                     if record_rays:
                         seg = []
-                        col = trace_recorded(r, scene, ray, seg)
+                        col = trace_recorded(r, scene, ray, seg, stream)
                         for j, rec in enumerate(seg):
                             rec.update(x=x, y=y, s=s, seg=j)
                         recs.extend(seg)
                     else:
-                        col = r.raytrace(ray)
+                        col = trace_hooked(r, scene, ray, stream)
                     out[ix, y, s] = tuple(col)
                 except (IndexError, ValueError):
                     status[ix, y, s] = 1
