@@ -171,6 +171,15 @@ int rt_reset_stats(rt_ctx *ctx);
  * DEVICE: one Philox4x32-10 block per path segment, five 24-bit fields each. */
 int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t seed, int32_t n_segments, float *out_host);
 
+/* Parity / diagnostic hook: traces n_paths whole paths, one device thread each, with the same
+ * device functions the render kernel runs (Camera.get_ray + Renderer.raytrace, camera.py:39-50,
+ * renderer.py:21-79), and records every segment.  xys = [n_paths][3] (x, y, sample index).  Outputs
+ * are host arrays; per-segment arrays hold max_bounces + 1 entries per path: hit object / primitive
+ * (-1 = miss), which code produced the hit (see rt_intersect_batch), depth, ray origin, direction. */
+int rt_debug_trace_paths(rt_ctx *ctx, int32_t n_paths, const int32_t *xys, int32_t width, int32_t height,
+                         int32_t max_bounces, uint64_t seed, float *rgb, int32_t *n_seg, int32_t *seg_obj,
+                         int32_t *seg_prim, int32_t *seg_how, float *seg_t, float *seg_org, float *seg_dir);
+
 #ifdef __cplusplus
 }
 #endif

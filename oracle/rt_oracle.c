@@ -18,6 +18,14 @@
  * vec3.py:14-16 per bounce; see orc_uniform).  The golden
  * generator injects the very same stream into the upstream code, so both sides see one sequence.
  *
+ * Optional "origin rule" (orc_set_origin_rule(1), OFF by default): the HIP kernels carry the
+ * primitive a bounce ray starts on and never re-hit it at depth ~0 (the originating triangle is
+ * skipped; of the originating sphere only the far root counts, and only for a ray heading into
+ * it).  Upstream instead relies on `depth > 1e-10`, which on huge spheres lets round-off through
+ * ("acne": ~2 % of the ground hits of random_spheres re-hit the ground at t ~ 1e-10).  With the
+ * rule ON this file restates the kernels' semantics instead of upstream's, so that the two
+ * effects (acne / float32 arithmetic) can be measured apart.
+ *
  * Deliberate deviations from upstream (each counted in orc_counters):
  *   - sky lookup clamps asin's argument to [-1,1] and the texel index to the image; upstream raises
  *     (IndexError at u == 1.0, ValueError from int(nan)) and silently drops the tile
@@ -191,10 +199,15 @@ static int tri_hit(const double *tv, v3 o, v3 d, double *t, v3 *n, v3 *p) {
     return 0;
 }
 
+static int g_origin_rule = 0;
+void orc_set_origin_rule(int on) { g_origin_rule = on; }
+
 /* Scene.intersect (src/raytracing/scene.py:23-27): all hits with depth > 1e-10, stable-sorted by
  * depth; only hits[0] is consumed (renderer.py:36), i.e. the first minimum in object order, then
- * per-object hit order.  Returns the number of hits that survive the depth filter. */
-static int scene_intersect(const rt_scene_desc *s, v3 o, v3 d, hit_rec *best) {
+ * per-object hit order.  Returns the number of hits that survive the depth filter.
+ * origin = global id of the primitive the ray starts on (used only under the origin rule). */
+static int scene_intersect(const rt_scene_desc *s, v3 o, v3 d, hit_rec *best, int origin) {
+    if (!g_origin_rule) origin = -1;
     int n_hits = 0;
     best->obj = -1; best->prim = -1; best->gprim = -1; best->t = INFINITY;
     for (int oi = 0; oi < s->n_objects; ++oi) {
@@ -204,6 +217,11 @@ static int scene_intersect(const rt_scene_desc *s, v3 o, v3 d, hit_rec *best) {
             int k = sphere_hits(s->spheres + 4 * (size_t)si, o, d, t, n, p, root);
             for (int j = 0; j < k; ++j) {
                 if (!(t[j] > 1e-10)) continue;
+                if (si == origin) { /* far root only, and only when heading into the sphere */
+                    const double *sp = s->spheres + 4 * (size_t)si;
+                    v3 ro = vsub(o, V(sp[0], sp[1], sp[2]));
+                    if (root[j] != 1 || !(2 * vdot(ro, d) < 0)) continue;
+                }
                 n_hits++;
                 if (t[j] < best->t) {
                     best->t = t[j]; best->obj = oi; best->prim = root[j]; best->gprim = si;
@@ -215,6 +233,7 @@ static int scene_intersect(const rt_scene_desc *s, v3 o, v3 d, hit_rec *best) {
             if (!aabb_gate(s->mesh_aabb + 6 * (size_t)mi, o, d)) continue;
             for (int ti = s->mesh_tri_begin[mi]; ti < s->mesh_tri_begin[mi + 1]; ++ti) {
                 double t; v3 n, p;
+                if (s->n_spheres + ti == origin) continue;
                 if (!tri_hit(s->tri_verts + 9 * (size_t)ti, o, d, &t, &n, &p)) continue;
                 if (!(t > 1e-10)) continue;
                 n_hits++;
@@ -230,12 +249,12 @@ static int scene_intersect(const rt_scene_desc *s, v3 o, v3 d, hit_rec *best) {
 
 /* exported: closest hit of n rays.  gprim = sphere index, or n_spheres + global triangle index. */
 void orc_intersect_batch(const rt_scene_desc *s, int64_t n, const double *org, const double *dir,
-                         int32_t *obj, int32_t *prim, int32_t *gprim, double *t, double *normal,
-                         double *pos, int32_t *n_hits) {
+                         const int32_t *origin_prim, int32_t *obj, int32_t *prim, int32_t *gprim,
+                         double *t, double *normal, double *pos, int32_t *n_hits) {
     for (int64_t i = 0; i < n; ++i) {
         hit_rec h;
         int k = scene_intersect(s, V(org[3 * i], org[3 * i + 1], org[3 * i + 2]),
-                                V(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), &h);
+                                V(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), &h, origin_prim ? origin_prim[i] : -1);
         obj[i] = h.obj; prim[i] = h.prim; if (gprim) gprim[i] = h.gprim;
         t[i] = h.obj >= 0 ? h.t : INFINITY;
         if (normal) { normal[3 * i] = h.obj >= 0 ? h.n.x : 0; normal[3 * i + 1] = h.obj >= 0 ? h.n.y : 0; normal[3 * i + 2] = h.obj >= 0 ? h.n.z : 0; }
@@ -353,12 +372,13 @@ static v3 trace_path(const rt_scene_desc *s, v3 o, v3 d, int max_bounces, draw_s
     v3 colors[64];
     int n_colors = 0;
     int inside = 0;
+    int origin = -1;
     v3 terminal = V(0, 0, 0);
     for (int depth = 0;; ++depth) {
         if (depth > max_bounces) { terminal = V(0, 0, 0); break; } /* renderer.py:29-30 */
         hit_rec h;
         (*rays)++;
-        scene_intersect(s, o, d, &h); /* renderer.py:32 */
+        scene_intersect(s, o, d, &h, origin); /* renderer.py:32 */
         begin_segment(rng, (uint32_t)depth + 1);
         if (tr) {
             int i = tr->n++;
@@ -397,7 +417,7 @@ static v3 trace_path(const rt_scene_desc *s, v3 o, v3 d, int max_bounces, draw_s
             nd = refract_dir(d, N, ior);
             inside = !inside;
         }
-        o = h.pos; d = nd; /* renderer.py:73-76: new ray starts exactly at the hit position */
+        o = h.pos; d = nd; origin = h.gprim; /* renderer.py:73-76: new ray starts exactly at the hit position */
     }
     v3 L = terminal;
     for (int i = n_colors - 1; i >= 0; --i) L = vprod(colors[i], L); /* renderer.py:78 */

@@ -23,7 +23,8 @@ RT_ERR_STOPPED = 5
 # every symbol include/raytracing_amd.h declares
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
-           "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms"]
+           "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms",
+           "rt_debug_trace_paths"]
 
 
 class RtRenderParams(C.Structure):
@@ -82,6 +83,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
     lib.rt_reset_stats.argtypes = [vp]
     lib.rt_debug_uniforms.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int32, fp]
+    lib.rt_debug_trace_paths.argtypes = [vp, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+                                         fp, ip, ip, ip, ip, fp, fp, fp]
     if path is None:
         _lib = lib
     return lib
@@ -191,4 +194,19 @@ class HipBackend:
         out = np.empty((n_segments, 5), dtype=np.float32)
         self._check(self.lib.rt_debug_uniforms(self.handle, pixel, sample, seed, n_segments,
                                                out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def trace_paths(self, xys, width: int, height: int, max_bounces: int, seed: int) -> dict:
+        """Whole paths with per-segment records (diagnostics / parity tests)."""
+        xys = np.ascontiguousarray(xys, dtype=np.int32).reshape(-1, 3)
+        n, cap = xys.shape[0], max_bounces + 1
+        out = dict(rgb=np.empty((n, 3), np.float32), n_seg=np.empty(n, np.int32), obj=np.empty((n, cap), np.int32),
+                   prim=np.empty((n, cap), np.int32), how=np.empty((n, cap), np.int32), t=np.empty((n, cap), np.float32),
+                   org=np.empty((n, cap, 3), np.float32), dir=np.empty((n, cap, 3), np.float32))
+        ip, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        self._check(self.lib.rt_debug_trace_paths(
+            self.handle, n, xys.ctypes.data_as(ip), width, height, max_bounces, seed & 0xFFFFFFFFFFFFFFFF,
+            out["rgb"].ctypes.data_as(fp), out["n_seg"].ctypes.data_as(ip), out["obj"].ctypes.data_as(ip),
+            out["prim"].ctypes.data_as(ip), out["how"].ctypes.data_as(ip), out["t"].ctypes.data_as(fp),
+            out["org"].ctypes.data_as(fp), out["dir"].ctypes.data_as(fp)))
         return out

@@ -190,8 +190,8 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             r.nx = (float)N.x; r.ny = (float)N.y; r.nz = (float)N.z; r.kn = (float)(-dot(N, a));
             r.e1x = (float)e1.x; r.e1y = (float)e1.y; r.e1z = (float)e1.z; r.k1 = (float)(-dot(e1, a));
             r.e2x = (float)e2.x; r.e2y = (float)e2.y; r.e2z = (float)e2.z; r.k2 = (float)(-dot(e2, a));
-            r.cb = up(32.0 * nl * std::max(norm(e1), norm(e2)));
-            r.ct = up(16.0 * nl);
+            r.cb = (float)(norm(e1) + norm(e2));   // finished below, once the scene radius is known
+            r.ct = up(1.01 * nl);
             const double noise = 16.0 * (double)kU * nl;
             r.det_lo = (float)std::max(0.0, 1e-6 - noise) * (1.0f - 4.0f * kU);
             x.det_hi = up(1e-6 + noise);
@@ -208,6 +208,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     }
 
     // ---- spheres -----------------------------------------------------------------------------
+    // (the scene radius also takes the small spheres; triangle rows are finished after this block)
     std::vector<double> radii(d->n_spheres);
     for (int s = 0; s < d->n_spheres; ++s) radii[s] = std::fabs(d->spheres[4 * (size_t)s + 3]);
     double median_r = 0;
@@ -233,6 +234,18 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         sph_all[s] = row;
         if (is_big) big.push_back(s);
         else { sph_small.push_back(row); scene_radius = std::max(scene_radius, norm1(ctr) + 3.0 * r); }
+    }
+
+    // barycentric bound constant: cb = 2.25 (|e1|+|e2|) |N| + 2 |N| / S_min, S_min = scene radius
+    {
+        const double smin = std::max(scene_radius, 1e-30);
+        auto finish = [&](TriRow &r) {
+            if (!(r.det_lo < INFINITY)) return;
+            const double nl = (double)r.ct / 1.01;
+            r.cb = up(1.01 * (2.25 * (double)r.cb * nl + 2.0 * nl / smin));
+        };
+        for (auto &r : rows_live) finish(r);
+        for (auto &r : rows_all) finish(r);
     }
 
     // ---- materials, environment ---------------------------------------------------------------
@@ -286,6 +299,10 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         S.cam_pos[k] = (float)d->cam_pos[k]; S.cam_right[k] = (float)d->cam_right[k];
         S.cam_up[k] = (float)d->cam_up[k]; S.cam_fwd[k] = (float)d->cam_forward[k];
     }
+    for (int k = 0; k < 3; ++k) {
+        S.cam64[k] = d->cam_pos[k]; S.cam64[3 + k] = d->cam_right[k]; S.cam64[6 + k] = d->cam_up[k]; S.cam64[9 + k] = d->cam_forward[k];
+    }
+    S.cam64[12] = d->cam_d; S.cam64[13] = d->cam_dof_strength; S.cam64[14] = d->cam_dof_dist;
     S.cam_d = (float)d->cam_d; S.dof_strength = (float)d->cam_dof_strength; S.dof_dist = (float)d->cam_dof_dist;
     S.dof_on = !(d->cam_dof_dist == 0 || d->cam_dof_strength == 0);   // camera.py:41
     S.sky = has_sky ? c->sky.as<uint32_t>() : nullptr; S.sky_w = has_sky ? d->sky_w : 0; S.sky_h = has_sky ? d->sky_h : 0;
@@ -321,17 +338,24 @@ __global__ __launch_bounds__(256) void k_intersect(const DevScene S, const Isect
     // representable in float32 are answered by the exact code on the doubles themselves.
     const bool f32_ray = (double)fox == ox && (double)foy == oy && (double)foz == oz && (double)fdx == dx &&
                          (double)fdy == dy && (double)fdz == dz;
-    SceneHit e; e.obj = -2;
-    Hit h; h.obj = -1; h.how = 2;
+    ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
+    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.how = 2;
     HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
     if (f32_ray) {
         Ray r = make_ray(S, fox, foy, foz, fdx, fdy, fdz, origin);
-        h = closest_hit<HAS_TRI, HAS_SPH, DETCUT>(S, r, cnt, &e);
+        h = closest_hit<HAS_TRI, HAS_SPH, DETCUT>(S, r, cnt, &e, false, PrimaryRef{});
     } else {
-        e = exact_scan(S, d3(ox, oy, oz), d3(dx, dy, dz), origin);
-        h.obj = e.obj; h.prim = e.prim; h.gprim = e.gprim; h.how = 2; cnt.exact = 1;
+        const D3 o64 = d3(ox, oy, oz), d64 = d3(dx, dy, dz);
+        ScanHit sh = exact_scan(S, o64, d64, origin);
+        cnt.exact = 1;
+        if (sh.gprim >= 0) e = exact_single(S, sh.gprim, o64, d64, origin);
+        if (e.hit) {
+            h.gprim = sh.gprim;
+            if (sh.gprim < S.n_spheres) { h.obj = S.sph_obj[sh.gprim]; h.prim = e.prim; }
+            else { const TriAux X = S.tri_aux[sh.gprim - S.n_spheres]; h.obj = X.obj; h.prim = X.face; }
+        }
     }
-    const bool have64 = e.obj != -2;
+    const bool have64 = e.hit;
     A.obj[i] = h.obj; A.prim[i] = h.prim;
     if (A.gprim) A.gprim[i] = h.gprim;
     if (A.how) A.how[i] = h.how;
@@ -570,5 +594,44 @@ extern "C" int rt_debug_uniforms(rt_ctx *c, uint32_t pixel, uint32_t sample, uin
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(out_host, b.p, (size_t)n_segments * 5 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// Whole paths, one per thread, with every segment recorded (parity tests; not a fast path).
+extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *xys, int32_t width, int32_t height,
+                                    int32_t max_bounces, uint64_t seed, float *rgb, int32_t *n_seg, int32_t *seg_obj,
+                                    int32_t *seg_prim, int32_t *seg_how, float *seg_t, float *seg_org, float *seg_dir) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (n_paths <= 0 || !xys || !rgb || !n_seg || !seg_obj || !seg_prim || !seg_how || !seg_t || !seg_org || !seg_dir ||
+        width <= 0 || height <= 0 || max_bounces < 0 || max_bounces > 62)
+        return fail(c, RT_ERR_INVALID_ARG, "rt_debug_trace_paths: bad arguments");
+    if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "rt_debug_trace_paths: no scene set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int cap = max_bounces + 1;
+    const size_t np = (size_t)n_paths, ns = np * cap;
+    DevBuf b_xys, b_rgb, b_n, b_obj, b_prim, b_how, b_t, b_org, b_dir;
+    HIP_TRY(c, b_xys.ensure(np * 12)); HIP_TRY(c, hipMemcpy(b_xys.p, xys, np * 12, hipMemcpyHostToDevice));
+    HIP_TRY(c, b_rgb.ensure(np * 12)); HIP_TRY(c, b_n.ensure(np * 4));
+    HIP_TRY(c, b_obj.ensure(ns * 4)); HIP_TRY(c, b_prim.ensure(ns * 4)); HIP_TRY(c, b_how.ensure(ns * 4)); HIP_TRY(c, b_t.ensure(ns * 4));
+    HIP_TRY(c, b_org.ensure(ns * 12)); HIP_TRY(c, b_dir.ensure(ns * 12));
+    HIP_TRY(c, hipMemset(b_obj.p, 0xFF, ns * 4)); HIP_TRY(c, hipMemset(b_prim.p, 0xFF, ns * 4)); HIP_TRY(c, hipMemset(b_how.p, 0xFF, ns * 4));
+    HIP_TRY(c, hipMemset(b_t.p, 0, ns * 4)); HIP_TRY(c, hipMemset(b_org.p, 0, ns * 12)); HIP_TRY(c, hipMemset(b_dir.p, 0, ns * 12));
+    TraceArgs A{};
+    A.n_paths = n_paths; A.width = width; A.height = height; A.max_bounces = max_bounces; A.seg_cap = cap;
+    A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32);
+    A.xys = b_xys.as<int32_t>(); A.rgb = b_rgb.as<float>(); A.n_seg = b_n.as<int32_t>(); A.seg_obj = b_obj.as<int32_t>();
+    A.seg_prim = b_prim.as<int32_t>(); A.seg_how = b_how.as<int32_t>(); A.seg_t = b_t.as<float>();
+    A.seg_org = b_org.as<float>(); A.seg_dir = b_dir.as<float>();
+    const DevScene S = c->S;
+    dispatch_variant(c->has_tri, c->has_sph, c->det_cut, [&](auto T, auto P, auto D) {
+        hipLaunchKernelGGL((k_trace_paths<decltype(T)::value, decltype(P)::value, decltype(D)::value>),
+                           dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, 0, S, A);
+    });
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(rgb, b_rgb.p, np * 12, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(n_seg, b_n.p, np * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(seg_obj, b_obj.p, ns * 4, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(seg_prim, b_prim.p, ns * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(seg_how, b_how.p, ns * 4, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(seg_t, b_t.p, ns * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(seg_org, b_org.p, ns * 12, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(seg_dir, b_dir.p, ns * 12, hipMemcpyDeviceToHost));
     return RT_OK;
 }

@@ -35,7 +35,8 @@ struct ExactHit {
 };
 
 // Sphere.intersect restricted to its first hit that survives Scene.intersect's depth filter.
-RT_DEV ExactHit exact_sphere(const double *sp, D3 o, D3 d, bool is_origin) {
+// want_geometry = false skips position and normal (callers that only rank by depth).
+RT_DEV ExactHit exact_sphere(const double *sp, D3 o, D3 d, bool is_origin, bool want_geometry = true) {
     ExactHit h; h.hit = false; h.prim = 0; h.t = 0; h.n = d3(0, 0, 0); h.pos = h.n;
     D3 c = d3(sp[0], sp[1], sp[2]);
     double radius = sp[3];
@@ -57,8 +58,10 @@ RT_DEV ExactHit exact_sphere(const double *sp, D3 o, D3 d, bool is_origin) {
         else return h;
     }
     h.hit = true; h.prim = root; h.t = t;
-    h.pos = dat(o, d, t);
-    h.n = dnormalize(dsub(h.pos, c));
+    if (want_geometry) {
+        h.pos = dat(o, d, t);
+        h.n = dnormalize(dsub(h.pos, c));
+    }
     return h;
 }
 
@@ -76,7 +79,7 @@ RT_DEV bool exact_aabb(const double *bb, D3 o, D3 d) {
 }
 
 // Mesh.intersect_tri + the depth filter
-RT_DEV ExactHit exact_tri(const double *tv, D3 o, D3 d) {
+RT_DEV ExactHit exact_tri(const double *tv, D3 o, D3 d, bool want_geometry = true) {
     ExactHit h; h.hit = false; h.prim = 0; h.t = 0; h.n = d3(0, 0, 0); h.pos = h.n;
     D3 pa = d3(tv[0], tv[1], tv[2]), pb = d3(tv[3], tv[4], tv[5]), pc = d3(tv[6], tv[7], tv[8]);
     D3 ab = dsub(pb, pa), ac = dsub(pc, pa);
@@ -91,18 +94,21 @@ RT_DEV ExactHit exact_tri(const double *tv, D3 o, D3 d) {
     double v = -ddot(ab, dao) * inv_det;
     double w = 1 - u - v;
     if (dst >= 0 && u >= 0 && v >= 0 && w >= 0 && dst > 1e-10) {
-        h.hit = true; h.t = dst; h.pos = dat(o, d, dst); h.n = dnormalize(nrm);
+        h.hit = true; h.t = dst;
+        if (want_geometry) { h.pos = dat(o, d, dst); h.n = dnormalize(nrm); }
     }
     return h;
 }
 
-struct SceneHit {
-    int32_t obj;     // -1 = miss
-    int32_t prim;    // face index / sphere root
-    int32_t gprim;   // sphere index, or n_spheres + triangle index
-    double t;
-    D3 n, pos;
-};
+// Depth only, for a triangle the float32 filter has already proven to be hit (mesh.py:117-130).
+RT_DEV double exact_tri_depth(const double *tv, D3 o, D3 d) {
+    D3 pa = d3(tv[0], tv[1], tv[2]), pb = d3(tv[3], tv[4], tv[5]), pc = d3(tv[6], tv[7], tv[8]);
+    D3 nrm = dcross(dsub(pb, pa), dsub(pc, pa));
+    double det = -ddot(d, nrm);
+    return ddot(nrm, dsub(o, pa)) * (1 / det);
+}
+
+struct ScanHit { int32_t gprim; double t; };   // gprim < 0: miss
 
 // One primitive by global id, with its mesh's bounding-box gate.
 RT_DEV ExactHit exact_single(const DevScene &S, int32_t gprim, D3 o, D3 d, int32_t origin) {
@@ -115,26 +121,22 @@ RT_DEV ExactHit exact_single(const DevScene &S, int32_t gprim, D3 o, D3 d, int32
 }
 
 // Scene.intersect(ray)[0]: first minimum of depth in object order, then per-object hit order.
-RT_DEV SceneHit exact_scan(const DevScene &S, D3 o, D3 d, int32_t origin) {
-    SceneHit best; best.obj = -1; best.prim = -1; best.gprim = -1; best.t = __builtin_inf();
-    best.n = d3(0, 0, 0); best.pos = best.n;
+// Returns the identity and depth only; the caller re-evaluates the winner for position / normal
+// (same arithmetic, so the same depth).
+RT_DEV ScanHit exact_scan(const DevScene &S, D3 o, D3 d, int32_t origin) {
+    ScanHit best; best.gprim = -1; best.t = __builtin_inf();
     for (int oi = 0; oi < S.n_objects; ++oi) {
         int idx = S.obj_index[oi];
         if (S.obj_kind[oi] == 0) {
-            ExactHit h = exact_sphere(S.sph64 + 4 * (size_t)idx, o, d, idx == origin);
-            if (h.hit && h.t < best.t) {
-                best.obj = oi; best.prim = h.prim; best.gprim = idx; best.t = h.t; best.n = h.n; best.pos = h.pos;
-            }
+            ExactHit h = exact_sphere(S.sph64 + 4 * (size_t)idx, o, d, idx == origin, false);
+            if (h.hit && h.t < best.t) { best.gprim = idx; best.t = h.t; }
         } else {
             if (!exact_aabb(S.aabb64 + 6 * (size_t)idx, o, d)) continue;
             int t0 = S.mesh_tri_begin[idx], t1 = S.mesh_tri_begin[idx + 1];
             for (int ti = t0; ti < t1; ++ti) {
                 if (S.n_spheres + ti == origin) continue;
-                ExactHit h = exact_tri(S.tri64 + 9 * (size_t)ti, o, d);
-                if (h.hit && h.t < best.t) {
-                    best.obj = oi; best.prim = ti - t0; best.gprim = S.n_spheres + ti; best.t = h.t;
-                    best.n = h.n; best.pos = h.pos;
-                }
+                ExactHit h = exact_tri(S.tri64 + 9 * (size_t)ti, o, d, false);
+                if (h.hit && h.t < best.t) { best.gprim = S.n_spheres + ti; best.t = h.t; }
             }
         }
     }

@@ -69,15 +69,15 @@ RT_DEV SphRow load_sph_row_uniform(const SphRow *rows, int i) {
 
 constexpr uint32_t kKeyNone = 0x7F800000u;   // keys at or above +inf's pattern mean "no candidate"
 constexpr float kInf = __builtin_inff();
-constexpr float kBandM2 = 54.0f * kU;        // discriminant bound, |ro|^2 coefficient (2x the derived 27u)
 constexpr float kTCertain = 1e-9f;           // a depth bound above this certainly passes upstream's 1e-10 filter
+constexpr float kRelAccept = 9.5e-6f;          // float32 depth / normal accepted when its error bound is below this
 
 // A ray prepared for the filter.  All bounds assume 1/2 <= |d| <= 2 and no exactly-zero component
 // of d (such rays go straight to the exact code: see ray_needs_exact).
 struct Ray {
     float ox, oy, oz, dx, dy, dz;
     float a, inv_a, dlen;  // d.d, 1/(d.d), |d|
-    float cr;              // 2 u S D : S = |o|_1 + scene_radius, D = max(|d|, 1/|d|)
+    float c4, c7;          // triangle bounds: q = c7 |t| + c4 with c4 = 4u S, c7 = 7u |d|, S = |o|_1 + scene_radius
     float band0;           // crude per-ray discriminant bound for the in-loop sphere test
     int32_t origin;        // global id of the primitive the ray starts on, -1 = none
 };
@@ -88,9 +88,11 @@ RT_DEV Ray make_ray(const DevScene &S, float ox, float oy, float oz, float dx, f
     r.a = fma_(dz, dz, fma_(dy, dy, dx * dx));
     r.inv_a = rcp_(r.a);
     r.dlen = sqrt_(r.a);
-    float D = max_(r.dlen, rsq_(r.a)) * 1.0001f;
     float Sr = abs_(ox) + abs_(oy) + abs_(oz) + S.scene_radius;
-    r.cr = 2.0f * kU * Sr * D;
+    // 1.3x: a primary ray is the float32 rounding of the double-precision camera ray the exact
+    // code uses (u per component of o and d), which the derivation above does not include
+    r.c4 = 1.3f * 4.04f * kU * Sr;
+    r.c7 = 1.3f * 7.07f * kU * r.dlen;
     r.band0 = 72.0f * kU * r.a * Sr * Sr;
     r.origin = origin;
     return r;
@@ -104,10 +106,17 @@ RT_DEV bool ray_needs_exact(const Ray &r) {
 
 // ---------------------------------------------------------------------------------------------
 // Triangles
+//
+// Error model (u = 2^-24, every operation rounds once, table entries are rounded doubles):
+//   nd = N.d            |err| <= 4u |N||d|
+//   no = N.o + kN       |err| <= 4u |N| (|a| + |o|)
+//   t  = -no * rcp(nd)  |err| <= u k [4 (|a|+|o|)/|d| + 7 |t|],   k = |N||d| / |nd|  (1 / |cos|)
+//   u,v at p = o + t d  |err| <= |e| u k [9 (|a|+|o|) + 12 |t||d|]
+// With q = 4u S + 7u |t||d| (S >= |a| + |o|) and g = q / |nd|:   t bound = g |N|,
+// barycentric bound (for min(u, v, 1-u-v)) = g * cb,  cb = 2.25 (|e1|+|e2|) |N| + 2 |N| / S_min.
 // ---------------------------------------------------------------------------------------------
 struct TriEval { float m, t, g, nd; };
 
-// 21 VALU instructions: the arithmetic of mesh.py:122-133 restated at the hit point.
 RT_DEV TriEval tri_eval(const TriRow &T, const Ray &r) {
     TriEval e;
     e.nd = fma_(T.nz, r.dz, fma_(T.ny, r.dy, T.nx * r.dx));
@@ -119,7 +128,7 @@ RT_DEV TriEval tri_eval(const TriRow &T, const Ray &r) {
     float v = fma_(T.e2z, pz, fma_(T.e2y, py, fma_(T.e2x, px, T.k2)));
     float w = (1.0f - u) - v;
     e.m = min_(min_(u, v), w);
-    e.g = r.cr * abs_(inv);
+    e.g = fma_(r.c7, abs_(e.t), r.c4) * abs_(inv);
     return e;
 }
 
@@ -131,25 +140,35 @@ RT_DEV void best_insert(Best &b, uint32_t key) {
 }
 
 template <bool DETCUT>
+RT_DEV void tri_candidate(const TriRow &T, const Ray &r, Best &b, uint32_t keep_mask) {
+    TriEval e = tri_eval(T, r);
+    float mp = fma_(e.g, T.cb, e.m);
+    float thi = fma_(e.g, T.ct, e.t);
+    float tlo = fma_(-e.g, T.ct, e.t);
+    float x = min_(mp, thi);
+    float y = x * (-kInf);                 // x < 0 -> +inf (not a candidate); x >= 0 -> -inf / NaN
+    float tl = max_(max_(tlo, 0.0f), y);   // NaNs drop out of max: a NaN anywhere keeps the candidate
+    uint32_t key = (f2u(tl) & keep_mask) | (uint32_t)T.gprim;
+    bool kill = (T.gprim == r.origin);
+    if (DETCUT) kill = kill || !(abs_(e.nd) >= T.det_lo);
+    key = kill ? 0xFFFFFFFFu : key;
+    best_insert(b, key);
+}
+
+// Brute-force loop over the live triangles.  The next row's scalar load is issued before the
+// current row's arithmetic, so its latency hides behind ~35 vector instructions.
+template <bool DETCUT>
 RT_DEV void search_tris(const DevScene &S, const Ray &r, Best &b, uint32_t keep_mask) {
     const int n = S.n_tri_rows;
+    if (n <= 0) return;
     const TriRow *rows = S.tri_rows;
-#pragma unroll 2
-    for (int i = 0; i < n; ++i) {
-        const TriRow T = load_tri_row_uniform(rows, i);
-        TriEval e = tri_eval(T, r);
-        float mp = fma_(e.g, T.cb, e.m);
-        float thi = fma_(e.g, T.ct, e.t);
-        float tlo = fma_(-e.g, T.ct, e.t);
-        float x = min_(mp, thi);
-        float y = x * (-kInf);                 // x < 0 -> +inf (not a candidate); x >= 0 -> -inf / NaN
-        float tl = max_(max_(tlo, 0.0f), y);   // NaNs drop out of max: a NaN anywhere keeps the candidate
-        uint32_t key = (f2u(tl) & keep_mask) | (uint32_t)T.gprim;
-        bool kill = (T.gprim == r.origin);
-        if (DETCUT) kill = kill || !(abs_(e.nd) >= T.det_lo);
-        key = kill ? 0xFFFFFFFFu : key;
-        best_insert(b, key);
+    TriRow cur = load_tri_row_uniform(rows, 0);
+    for (int i = 1; i < n; ++i) {
+        const TriRow nxt = load_tri_row_uniform(rows, i);
+        tri_candidate<DETCUT>(cur, r, b, keep_mask);
+        cur = nxt;
     }
+    tri_candidate<DETCUT>(cur, r, b, keep_mask);
 }
 
 // Winner re-evaluation.  status: 0 accept float32 result, 1 identity certain but imprecise,
@@ -163,7 +182,7 @@ RT_DEV Verdict judge_tri(const DevScene &S, int32_t ti, const Ray &r) {
     bool certain = (e.m - bb >= 0.0f) && (e.t - bt > kTCertain) && (abs_(e.nd) >= S.tri_aux[ti].det_hi);
     Verdict v;
     v.t = e.t; v.thi = e.t + bt;
-    v.status = !certain ? 2 : ((bt <= 2e-6f * e.t) ? 0 : 1);
+    v.status = !certain ? 2 : ((bt <= kRelAccept * e.t) ? 0 : 1);
     return v;
 }
 
@@ -183,21 +202,23 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
     float lx = fma_(tc, r.dx, rox), ly = fma_(tc, r.dy, roy), lz = fma_(tc, r.dz, roz);
     float l2 = fma_(lz, lz, fma_(ly, ly, lx * lx));
     float h2 = P.r2 - l2;
-    // per-component error of l: rounding of ro (u|ro|), of the centre (u|c|), of tc*d (~4u|ro|)
-    float dl = kU * (8.0f * mlen + 2.0f * P.cn);
-    float dh2 = 4.0f * sqrt_(l2) * dl + 3.0f * dl * dl + 8.0f * kU * (l2 + P.r2);
+    // per-component error of l: rounding of ro (u|ro|), of the centre (u|c|), of tc*d and its sum (~4u|ro|)
+    const float o1 = abs_(r.ox) + abs_(r.oy) + abs_(r.oz);   // a rounded primary-ray origin is off by u|o|
+    float dl = kU * (7.0f * mlen + 1.5f * P.cn + o1);
+    float dh2 = 3.5f * sqrt_(l2) * dl + 3.0f * dl * dl + 5.0f * kU * (l2 + P.r2);
     float hhi = h2 + dh2, hlo = h2 - dh2;
     o.maybe = hhi >= 0.0f;
     o.surely = hlo > 0.0f;
     float shi = sqrt_(max_(hhi, 0.0f) * r.inv_a) * (1.0f + 8.0f * kU);
     float slo = sqrt_(max_(hlo, 0.0f) * r.inv_a) * (1.0f - 8.0f * kU);
     float smid = sqrt_(max_(h2, 0.0f) * r.inv_a);
-    // error of tc: b has abs error <= u|d|(5|ro| + 2|c|), a and 1/a rel error <= 6u
-    float eb = 2.0f * kU * r.dlen * (5.0f * mlen + 2.0f * P.cn) * r.inv_a + 8.0f * kU * abs_(tc);
+    // b = ro.d has abs error <= u|d|(5|ro| + 2|c|); a and 1/a carry <= 6u relative
+    float ebb = kU * r.dlen * (6.0f * mlen + 2.0f * P.cn + o1);
+    float eb = ebb * r.inv_a * 1.001f + 7.0f * kU * abs_(tc);
     o.t1lo = tc - shi - eb; o.t1hi = tc - slo + eb;
     o.t2lo = tc + slo - eb; o.t2hi = tc + shi + eb;
     o.t1 = tc - smid; o.t2 = tc + smid;
-    o.b = b; o.eb = 2.0f * kU * r.dlen * (5.0f * mlen + 2.0f * P.cn);
+    o.b = b; o.eb = ebb;
     return o;
 }
 
@@ -245,9 +266,10 @@ RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r) {
     }
     if (!certain) return v;
     v.root = root; v.t = t; v.thi = hi;
-    // precise enough?  depth to 2e-6 relative, and the normal (pos - c)/r to ~3e-6
-    float perr = 0.5f * (hi - lo) * r.dlen + 4.0f * kU * (abs_(r.ox) + abs_(r.oy) + abs_(r.oz) + P.cn + t * r.dlen);
-    bool precise = (0.5f * (hi - lo) <= 2e-6f * t) && (perr <= 3e-6f * P.r);
+    // precise enough?  depth to kRelAccept relative, and the normal (pos - c)/r to kRelAccept
+    float half = 0.5f * (hi - lo);
+    float perr = half * r.dlen + 3.0f * kU * (abs_(r.ox) + abs_(r.oy) + abs_(r.oz) + P.cn + t * r.dlen);
+    bool precise = (half <= kRelAccept * t) && (perr <= kRelAccept * P.r);
     v.status = precise ? 0 : 1;
     return v;
 }
@@ -258,82 +280,97 @@ RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r) {
 struct Hit {
     int32_t obj, prim, gprim;   // obj < 0: miss
     float t, nx, ny, nz, px, py, pz;
-    int32_t how;                // 0 float32 fast path, 1 refined in double, 2 exact scene scan
+    int32_t how;                // 0 float32 filter alone, 1 winner re-evaluated in double, 2 exact scene scan
 };
 
 struct HitCounters { uint32_t exact, refine; };
 
-RT_DEV void hit_from_exact_scan(const DevScene &S, D3 o, D3 d, int32_t origin, Hit &h, SceneHit *keep) {
-    SceneHit e = exact_scan(S, o, d, origin);
-    if (keep) *keep = e;
-    h.how = 2; h.obj = e.obj; h.prim = e.prim; h.gprim = e.gprim;
-    h.t = (float)e.t; h.nx = (float)e.n.x; h.ny = (float)e.n.y; h.nz = (float)e.n.z;
-    h.px = (float)e.pos.x; h.py = (float)e.pos.y; h.pz = (float)e.pos.z;
-}
+// The exact code's view of a ray.  Bounce rays and caller-supplied rays ARE their float32 values;
+// a primary ray is the float32 rounding of the camera ray upstream computes in double precision
+// (camera.py:39-50), and the exact code re-derives that double-precision ray from the pixel so
+// that rays which graze an edge resolve as upstream resolves them.
+struct PrimaryRef { int32_t x, y, W, H; uint32_t key0, key1; };
 
-// `keep`, when given, receives the double-precision record whenever the exact code produced the hit.
+RT_DEV void camera_ray64(const DevScene &S, const PrimaryRef &pr, D3 &o, D3 &d);   // rt_render.h
+
+// `e64`, when given, receives the double-precision record whenever the exact code produced the hit
+// (e64->hit says whether it did).  `primary` identifies the pixel of a camera ray (is_primary).
 template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
-RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, SceneHit *keep) {
+RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactHit *e64, bool is_primary, const PrimaryRef primary) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
-    const D3 o64 = d3(r.ox, r.oy, r.oz), d64 = d3(r.dx, r.dy, r.dz);
-    if (keep) keep->obj = -2;
-    if (ray_needs_exact(r)) {
-        cnt.exact++;
-        hit_from_exact_scan(S, o64, d64, r.origin, h, keep);
-        return h;
-    }
-    const uint32_t keep_mask = ~S.key_mask;
-    Best b; b.k0 = 0xFFFFFFFFu; b.k1 = 0xFFFFFFFFu;
-    if (HAS_SPH) {
-        search_spheres(S, r, b, keep_mask);
-        for (int i = 0; i < S.n_big_sph; ++i) {   // the few huge spheres: double precision throughout
-            int si = S.big_sph[i];
-            ExactHit e = exact_sphere(S.sph64 + 4 * (size_t)si, o64, d64, si == r.origin);
-            float tl = (float)e.t * (1.0f - 4.0f * kU);
-            uint32_t key = e.hit ? ((f2u(tl) & keep_mask) | (uint32_t)si) : 0xFFFFFFFFu;
-            best_insert(b, key);
+    D3 o64 = d3(r.ox, r.oy, r.oz), d64 = d3(r.dx, r.dy, r.dz);
+    bool have64 = !is_primary;
+    ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
+    bool scan = ray_needs_exact(r);
+    int32_t gprim = -1; int root = 0; float t = kInf;
+    if (!scan) {
+        const uint32_t keep_mask = ~S.key_mask;
+        Best b; b.k0 = 0xFFFFFFFFu; b.k1 = 0xFFFFFFFFu;
+        if (HAS_SPH) {
+            search_spheres(S, r, b, keep_mask);
+            if (S.n_big_sph > 0 && !have64) { camera_ray64(S, primary, o64, d64); have64 = true; }
+            for (int i = 0; i < S.n_big_sph; ++i) {   // the few huge spheres: double precision throughout
+                int si = S.big_sph[i];
+                ExactHit eb = exact_sphere(S.sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
+                float tl = (float)eb.t * (1.0f - 4.0f * kU);
+                uint32_t key = eb.hit ? ((f2u(tl) & keep_mask) | (uint32_t)si) : 0xFFFFFFFFu;
+                best_insert(b, key);
+            }
+        }
+        if (HAS_TRI) search_tris<DETCUT>(S, r, b, keep_mask);
+        if (b.k0 < kKeyNone) {
+            gprim = (int32_t)(b.k0 & S.key_mask);
+            const float second_lo = u2f(b.k1 & keep_mask);
+            const bool has_second = b.k1 < kKeyNone;
+            int status; float thi;
+            if (gprim < S.n_spheres) {
+                SphVerdict v = judge_sphere(S, gprim, r);
+                status = v.status; t = v.t; thi = v.thi; root = v.root;
+            } else {
+                Verdict v = judge_tri(S, gprim - S.n_spheres, r);
+                status = v.status; t = v.t; thi = v.thi;
+            }
+            if (status == 1 && gprim >= S.n_spheres) {
+                // a triangle that is certainly the hit but whose float32 depth is too coarse (grazing
+                // incidence): only the depth is redone in double precision
+                cnt.refine++;
+                if (!have64) { camera_ray64(S, primary, o64, d64); have64 = true; }
+                t = (float)exact_tri_depth(S.tri64 + 9 * (size_t)(gprim - S.n_spheres), o64, d64);
+                thi = t * (1.0f + 2.0f * kU);
+                h.how = 1;
+            } else if (status != 0) {   // undecided, or an imprecise sphere: double precision for this primitive
+                cnt.refine++;
+                if (!have64) { camera_ray64(S, primary, o64, d64); have64 = true; }
+                e = exact_single(S, gprim, o64, d64, r.origin);
+                if (!e.hit) scan = true;            // the winner was not a hit after all
+                else { t = (float)e.t; thi = t * (1.0f + 2.0f * kU); root = e.prim; }
+            }
+            if (has_second && !(second_lo > thi)) scan = true;   // someone else may be in front, or tie
         }
     }
-    if (HAS_TRI) search_tris<DETCUT>(S, r, b, keep_mask);
-    if (b.k0 >= kKeyNone) return h;   // nothing can be hit: the filter is conservative
-
-    const int32_t gprim = (int32_t)(b.k0 & S.key_mask);
-    const float second_lo = u2f(b.k1 & keep_mask);   // +inf / NaN pattern when there is no runner-up
-    const bool has_second = b.k1 < kKeyNone;
-    int status; float t, thi; int root = 0;
-    if (gprim < S.n_spheres) {
-        SphVerdict v = judge_sphere(S, gprim, r);
-        status = v.status; t = v.t; thi = v.thi; root = v.root;
-    } else {
-        Verdict v = judge_tri(S, gprim - S.n_spheres, r);
-        status = v.status; t = v.t; thi = v.thi;
-    }
-    bool scan = false;
-    ExactHit e; e.hit = false;
-    if (status != 0) {   // undecided or imprecise: double precision for this one primitive
-        cnt.refine++;
-        e = exact_single(S, gprim, o64, d64, r.origin);
-        if (!e.hit) scan = true;            // the winner was not a hit after all
-        else { t = (float)e.t; thi = t * (1.0f + 2.0f * kU); root = e.prim; }
-    }
-    if (!scan && has_second && !(second_lo > thi)) scan = true;   // someone else may be in front, or tie
-    if (scan) {
+    if (scan) {   // upstream's Scene.intersect, literally, in double precision
         cnt.exact++;
-        hit_from_exact_scan(S, o64, d64, r.origin, h, keep);
-        return h;
+        h.how = 2;
+        if (!have64) { camera_ray64(S, primary, o64, d64); have64 = true; }
+        ScanHit sh = exact_scan(S, o64, d64, r.origin);
+        gprim = sh.gprim;
+        e.hit = false;
+        if (gprim >= 0) e = exact_single(S, gprim, o64, d64, r.origin);
+        if (!e.hit) gprim = -1;
     }
+    if (e64) *e64 = e;
+    if (gprim < 0) return h;
     h.gprim = gprim;
     if (gprim < S.n_spheres) {
-        h.obj = S.sph_obj[gprim]; h.prim = root;
+        h.obj = S.sph_obj[gprim]; h.prim = e.hit ? e.prim : root;
     } else {
         const TriAux A = S.tri_aux[gprim - S.n_spheres];
         h.obj = A.obj; h.prim = A.face;
     }
     if (e.hit) {
-        h.how = 1;
+        if (h.how == 0) h.how = 1;
         h.t = (float)e.t; h.nx = (float)e.n.x; h.ny = (float)e.n.y; h.nz = (float)e.n.z;
         h.px = (float)e.pos.x; h.py = (float)e.pos.y; h.pz = (float)e.pos.z;
-        if (keep) { keep->obj = h.obj; keep->prim = h.prim; keep->gprim = gprim; keep->t = e.t; keep->n = e.n; keep->pos = e.pos; }
         return h;
     }
     h.t = t;

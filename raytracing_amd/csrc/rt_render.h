@@ -72,29 +72,23 @@ RT_DEV void environment(const DevScene &S, float dx, float dy, float dz, float &
     r = (float)(c & 0xFFu) * k; g = (float)((c >> 8) & 0xFFu) * k; b = (float)((c >> 16) & 0xFFu) * k;
 }
 
-// Camera.get_ray (camera.py:39-50) for pixel (x, y) of a W x H image (renderer.py:96-103).
-RT_DEV void camera_ray(const DevScene &S, int x, int y, int W, int H, uint32_t key0, uint32_t key1,
-                       float &ox, float &oy, float &oz, float &dx, float &dy, float &dz) {
-    const float aspect = (float)H / (float)W;
-    float u = ((float)x + 0.5f) / (float)W * 2.0f - 1.0f;
-    float v = ((float)y + 0.5f) / (float)H * 2.0f * aspect - aspect;
-    float tx = fma_(S.cam_d, S.cam_fwd[0], fma_(v, S.cam_up[0], u * S.cam_right[0]));
-    float ty = fma_(S.cam_d, S.cam_fwd[1], fma_(v, S.cam_up[1], u * S.cam_right[1]));
-    float tz = fma_(S.cam_d, S.cam_fwd[2], fma_(v, S.cam_up[2], u * S.cam_right[2]));
-    float s = rsq_(fma_(tz, tz, fma_(ty, ty, tx * tx)));
-    dx = tx * s; dy = ty * s; dz = tz * s;
-    ox = S.cam_pos[0]; oy = S.cam_pos[1]; oz = S.cam_pos[2];
+// Camera.get_ray (camera.py:39-50) for pixel (x, y) of a W x H image (renderer.py:96-103), in
+// double precision and in upstream's operation order.  The kernels trace its float32 rounding.
+RT_DEV void camera_ray64(const DevScene &S, const PrimaryRef &pr, D3 &o, D3 &d) {
+    const double *c = S.cam64;
+    const D3 pos = d3(c[0], c[1], c[2]), right = d3(c[3], c[4], c[5]), up = d3(c[6], c[7], c[8]), fwd = d3(c[9], c[10], c[11]);
+    const double aspect = (double)pr.H / (double)pr.W;
+    const double u = (pr.x + 0.5) / pr.W * 2 - 1;
+    const double v = (pr.y + 0.5) / pr.H * 2 * aspect - aspect;
+    D3 t = d3(right.x * u + up.x * v + fwd.x * c[12], right.y * u + up.y * v + fwd.y * c[12], right.z * u + up.z * v + fwd.z * c[12]);
+    d = dnormalize(t);
+    o = pos;
     if (S.dof_on) {
-        Draws dr = segment_draws(key0, key1, 0);
-        float r1 = dr.f0, r2 = dr.f1;
-        float j1 = (r1 * 2.0f - 1.0f) * S.dof_strength, j2 = (r2 * 2.0f - 1.0f) * S.dof_strength;
-        float gx = fma_(dx, S.dof_dist, ox), gy = fma_(dy, S.dof_dist, oy), gz = fma_(dz, S.dof_dist, oz);
-        ox = fma_(S.cam_up[0], j2, fma_(S.cam_right[0], j1, ox));
-        oy = fma_(S.cam_up[1], j2, fma_(S.cam_right[1], j1, oy));
-        oz = fma_(S.cam_up[2], j2, fma_(S.cam_right[2], j1, oz));
-        tx = gx - ox; ty = gy - oy; tz = gz - oz;
-        s = rsq_(fma_(tz, tz, fma_(ty, ty, tx * tx)));
-        dx = tx * s; dy = ty * s; dz = tz * s;
+        const Draws dr = segment_draws(pr.key0, pr.key1, 0);
+        const double j1 = ((double)dr.f0 * 2 - 1) * c[13], j2 = ((double)dr.f1 * 2 - 1) * c[13];
+        const D3 target = d3(d.x * c[14] + pos.x, d.y * c[14] + pos.y, d.z * c[14] + pos.z);
+        o = d3(pos.x + right.x * j1 + up.x * j2, pos.y + right.y * j1 + up.y * j2, pos.z + right.z * j1 + up.z * j2);
+        d = dnormalize(dsub(target, o));
     }
 }
 
@@ -142,6 +136,53 @@ RT_DEV bool shade_bounce(const MatRow &m, const Hit &h, const Draws &u, float &d
     return true;
 }
 
+// Per-path state carried between segments.
+struct Path {
+    float ox, oy, oz, dx, dy, dz;   // current ray
+    float tr, tg, tb;               // product of surface colours so far (renderer.py:49)
+    uint32_t key0, key1;            // Philox key of this (pixel, sample)
+    int32_t depth;                  // closest-hit queries done so far
+    int32_t origin;                 // primitive the current ray starts on, -1 = camera
+    bool inside;                    // Ray.inside (ray.py:10), toggled by refraction
+};
+
+RT_DEV void path_begin(const DevScene &S, Path &p, int x, int y, int W, int H, uint32_t pixel, uint32_t sample,
+                       uint32_t seed_lo, uint32_t seed_hi) {
+    p.key0 = pixel ^ seed_lo; p.key1 = sample ^ seed_hi;
+    PrimaryRef pr; pr.x = x; pr.y = y; pr.W = W; pr.H = H; pr.key0 = p.key0; pr.key1 = p.key1;
+    D3 o, d;
+    camera_ray64(S, pr, o, d);
+    p.ox = (float)o.x; p.oy = (float)o.y; p.oz = (float)o.z; p.dx = (float)d.x; p.dy = (float)d.y; p.dz = (float)d.z;
+    p.tr = p.tg = p.tb = 1.0f; p.depth = 0; p.inside = false; p.origin = -1;
+}
+
+struct StepCounters { uint32_t sky, shaded; };
+
+// One segment: closest hit, then environment or one bounce.  Returns true while the path goes on;
+// when it returns false (er, eg, eb) is the terminal radiance to be multiplied by (tr, tg, tb).
+template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
+RT_DEV bool path_step(const DevScene &S, Path &p, int px, int py, int W, int H, int max_bounces, HitCounters &cnt,
+                      StepCounters &sc, float &er, float &eg, float &eb, Hit *hit_out) {
+    Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin);
+    PrimaryRef pr; pr.x = px; pr.y = py; pr.W = W; pr.H = H; pr.key0 = p.key0; pr.key1 = p.key1;
+    Hit h = closest_hit<HAS_TRI, HAS_SPH, DETCUT>(S, ray, cnt, nullptr, p.depth == 0, pr);
+    if (hit_out) *hit_out = h;
+    er = eg = eb = 0.0f;
+    if (h.obj < 0) {
+        environment(S, p.dx, p.dy, p.dz, er, eg, eb);
+        sc.sky++;
+        return false;
+    }
+    sc.shaded++;
+    const MatRow m = S.materials[h.obj];
+    const Draws u = segment_draws(p.key0, p.key1, (uint32_t)p.depth + 1u);
+    bool alive = shade_bounce(m, h, u, p.dx, p.dy, p.dz, p.inside, p.tr, p.tg, p.tb, er, eg, eb);
+    p.ox = h.px; p.oy = h.py; p.oz = h.pz; p.origin = h.gprim;
+    p.depth++;
+    if (alive && p.depth > max_bounces) { alive = false; er = eg = eb = 0.0f; }   // renderer.py:29-30
+    return alive;
+}
+
 RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 RT_DEV uint32_t rank_in(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -159,13 +200,12 @@ __global__ __launch_bounds__(256) void k_render(const DevScene S, const RenderAr
     uint32_t pixel = 0, slot = 0;
     int px = 0, py = 0, s_cur = 0, s_end = 0;
     float ar = 0, ag = 0, ab = 0;
-    // per-lane path state
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
-    float tr = 1, tg = 1, tb = 1;
-    int depth = 0; bool inside = false; int32_t origin = -1;
-    uint32_t key0 = 0, key1 = 0;
-    uint32_t n_rays = 0, n_paths = 0, n_sky = 0, n_shaded = 0;
+    Path p;
+    p.ox = p.oy = p.oz = 0; p.dx = p.dy = 0; p.dz = 1; p.tr = p.tg = p.tb = 1; p.key0 = p.key1 = 0;
+    p.depth = 0; p.origin = -1; p.inside = false;
+    uint32_t n_rays = 0, n_paths = 0;
     HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
+    StepCounters sc; sc.sky = 0; sc.shaded = 0;
     const uint32_t rect_px = (uint32_t)(A.rect_w * A.rect_h);
 
     for (;;) {
@@ -204,32 +244,16 @@ __global__ __launch_bounds__(256) void k_render(const DevScene S, const RenderAr
         if (have_job) {
             // ---- 2. start the next sample of this lane's pixel --------------------------------
             if (!in_path) {
-                key0 = pixel ^ A.seed_lo; key1 = (uint32_t)s_cur ^ A.seed_hi;
-                camera_ray(S, px, py, A.width, A.height, key0, key1, ox, oy, oz, dx, dy, dz);
-                tr = tg = tb = 1.0f; depth = 0; inside = false; origin = -1; in_path = true;
+                path_begin(S, p, px, py, A.width, A.height, pixel, (uint32_t)s_cur, A.seed_lo, A.seed_hi);
+                in_path = true;
                 n_paths++;
             }
-            // ---- 3. one path segment: closest hit, then shade ---------------------------------
-            Ray ray = make_ray(S, ox, oy, oz, dx, dy, dz, origin);
+            // ---- 3. one path segment ----------------------------------------------------------
             n_rays++;
-            Hit h = closest_hit<HAS_TRI, HAS_SPH, DETCUT>(S, ray, cnt, nullptr);
-            float er = 0, eg = 0, eb = 0;
-            bool alive;
-            if (h.obj < 0) {
-                environment(S, dx, dy, dz, er, eg, eb);
-                n_sky++;
-                alive = false;
-            } else {
-                n_shaded++;
-                const MatRow m = S.materials[h.obj];
-                const Draws u = segment_draws(key0, key1, (uint32_t)depth + 1u);
-                alive = shade_bounce(m, h, u, dx, dy, dz, inside, tr, tg, tb, er, eg, eb);
-                ox = h.px; oy = h.py; oz = h.pz; origin = h.gprim;
-                depth++;
-                if (alive && depth > A.max_bounces) { alive = false; er = eg = eb = 0.0f; }   // renderer.py:29-30
-            }
+            float er, eg, eb;
+            bool alive = path_step<HAS_TRI, HAS_SPH, DETCUT>(S, p, px, py, A.width, A.height, A.max_bounces, cnt, sc, er, eg, eb, nullptr);
             if (!alive) {
-                ar = fma_(tr, er, ar); ag = fma_(tg, eg, ag); ab = fma_(tb, eb, ab);
+                ar = fma_(p.tr, er, ar); ag = fma_(p.tg, eg, ag); ab = fma_(p.tb, eb, ab);
                 in_path = false;
                 s_cur++;
                 if (s_cur >= s_end) {
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(256) void k_render(const DevScene S, const RenderAr
     // ---- statistics: one atomic per counter per wave ------------------------------------------
     unsigned long long v[kStatCount] = {0};
     v[kStatRays] = n_rays; v[kStatPaths] = n_paths; v[kStatExact] = cnt.exact; v[kStatRefine] = cnt.refine;
-    v[kStatSky] = n_sky; v[kStatShaded] = n_shaded;
+    v[kStatSky] = sc.sky; v[kStatShaded] = sc.shaded;
     v[kStatSphTests] = (unsigned long long)n_rays * (uint32_t)(S.n_sph_rows + S.n_big_sph);
     v[kStatTriTests] = (unsigned long long)n_rays * (uint32_t)S.n_tri_rows;
 #pragma unroll
@@ -272,6 +296,45 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const RenderArgs A) {
     }
     float *dst = A.accum + 3 * ((size_t)px * A.height + py);
     dst[0] += r; dst[1] += g; dst[2] += b;
+}
+
+// Diagnostic / parity kernel: one thread traces one whole path and records every segment.
+struct TraceArgs {
+    int32_t n_paths, width, height, max_bounces, seg_cap;
+    uint32_t seed_lo, seed_hi;
+    const int32_t *xys;          // [n_paths][3] x, y, sample
+    float *rgb;                  // [n_paths][3] path radiance
+    int32_t *n_seg;              // [n_paths]
+    int32_t *seg_obj, *seg_prim, *seg_how;   // [n_paths][seg_cap]
+    float *seg_t;                // [n_paths][seg_cap]
+    float *seg_org, *seg_dir;    // [n_paths][seg_cap][3]
+};
+
+template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
+__global__ __launch_bounds__(256) void k_trace_paths(const DevScene S, const TraceArgs A) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n_paths) return;
+    const int x = A.xys[3 * i], y = A.xys[3 * i + 1], smp = A.xys[3 * i + 2];
+    Path p;
+    path_begin(S, p, x, y, A.width, A.height, (uint32_t)(x * A.height + y), (uint32_t)smp, A.seed_lo, A.seed_hi);
+    HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
+    StepCounters sc; sc.sky = 0; sc.shaded = 0;
+    float er = 0, eg = 0, eb = 0;
+    int n = 0;
+    for (;;) {
+        const size_t k = (size_t)i * A.seg_cap + n;
+        if (n < A.seg_cap) {
+            A.seg_org[3 * k] = p.ox; A.seg_org[3 * k + 1] = p.oy; A.seg_org[3 * k + 2] = p.oz;
+            A.seg_dir[3 * k] = p.dx; A.seg_dir[3 * k + 1] = p.dy; A.seg_dir[3 * k + 2] = p.dz;
+        }
+        Hit h;
+        bool alive = path_step<HAS_TRI, HAS_SPH, DETCUT>(S, p, x, y, A.width, A.height, A.max_bounces, cnt, sc, er, eg, eb, &h);
+        if (n < A.seg_cap) { A.seg_obj[k] = h.obj; A.seg_prim[k] = h.prim; A.seg_how[k] = h.how; A.seg_t[k] = h.t; }
+        n++;
+        if (!alive) break;
+    }
+    A.n_seg[i] = n;
+    A.rgb[3 * i] = p.tr * er; A.rgb[3 * i + 1] = p.tg * eg; A.rgb[3 * i + 2] = p.tb * eb;
 }
 
 }  // namespace rt

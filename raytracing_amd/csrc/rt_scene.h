@@ -81,6 +81,7 @@ struct DevScene {
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float cam_d, dof_strength, dof_dist;
     int32_t dof_on;
+    double cam64[15];         // pos, right, up, forward (3 each), d, dof_strength, dof_dist as the host holds them
     // environment: RGBA8 texels, row-major
     const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale;
 };

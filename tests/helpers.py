@@ -47,7 +47,8 @@ def oracle():
     lib.orc_sky_coords.argtypes = [_dp, _dp]
     lib.orc_environment.argtypes = [C.POINTER(RtSceneDesc), _dp, _dp]
     lib.orc_camera_ray.argtypes = [C.POINTER(RtSceneDesc), C.c_double, C.c_double, _dp, C.c_int, _dp, _dp]
-    lib.orc_intersect_batch.argtypes = [C.POINTER(RtSceneDesc), C.c_int64, _dp, _dp, _ip, _ip, _ip, _dp, _dp, _dp, _ip]
+    lib.orc_intersect_batch.argtypes = [C.POINTER(RtSceneDesc), C.c_int64, _dp, _dp, _ip, _ip, _ip, _ip, _dp, _dp, _dp, _ip]
+    lib.orc_set_origin_rule.argtypes = [C.c_int]
     lib.orc_trace_pixel.argtypes = [C.POINTER(RtSceneDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int,
                                     C.c_uint64, _dp, C.c_int, _dp, C.POINTER(C.c_uint64), _ip,
                                     _dp, _dp, _ip, _ip, _ip, _dp, _ip]
@@ -81,7 +82,18 @@ def load_npz(name: str):
     return z, meta
 
 
-def oracle_intersect(scene: PackedScene, org: np.ndarray, dirs: np.ndarray):
+class origin_rule:
+    """Context manager: the oracle restates the kernels' ray-origin rule instead of upstream's
+    `depth > 1e-10` self-intersection filter (see oracle/rt_oracle.c)."""
+
+    def __enter__(self):
+        oracle().orc_set_origin_rule(1)
+
+    def __exit__(self, *a):
+        oracle().orc_set_origin_rule(0)
+
+
+def oracle_intersect(scene: PackedScene, org: np.ndarray, dirs: np.ndarray, origin_prim=None):
     lib = oracle()
     n = org.shape[0]
     org = np.ascontiguousarray(org, np.float64)
@@ -94,7 +106,9 @@ def oracle_intersect(scene: PackedScene, org: np.ndarray, dirs: np.ndarray):
     pos = np.empty((n, 3), np.float64)
     nh = np.empty(n, np.int32)
     d = scene.desc()
-    lib.orc_intersect_batch(C.byref(d), n, _d(org), _d(dirs), _i(obj), _i(prim), _i(gprim), _d(t), _d(nrm), _d(pos), _i(nh))
+    op_arr = None if origin_prim is None else np.ascontiguousarray(origin_prim, np.int32)
+    op = None if op_arr is None else _i(op_arr)
+    lib.orc_intersect_batch(C.byref(d), n, _d(org), _d(dirs), op, _i(obj), _i(prim), _i(gprim), _d(t), _d(nrm), _d(pos), _i(nh))
     return dict(obj=obj, prim=prim, gprim=gprim, t=t, normal=nrm, pos=pos, n_hits=nh)
 
 
