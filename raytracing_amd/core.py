@@ -49,7 +49,6 @@ class Vec3:
     """
 
     __slots__ = ("x", "y", "z")
-    __array_ufunc__ = None  # numpy operands defer to the reflected operators below
 
     def __init__(self, *args) -> None:
         n = len(args)

@@ -1,0 +1,180 @@
+"""CPU tests of the host side: value types, OBJ loading, packing, the C ABI's symbol table, the
+post-processing chain, and that nothing renders without the HIP library / a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers as h
+from raytracing_amd import core, mesh, post_processing, raytracing
+from raytracing_amd.backend import lib as rtlib
+from raytracing_amd.backend.packer import PackedScene, RtSceneDesc, pack_scene
+
+
+def test_vec3_interface():
+    V = core.Vec3
+    a, b = V(1, 2, 3), V(4)
+    assert tuple(a + b) == (5, 6, 7) and tuple(a - b) == (-3, -2, -1) and tuple(-a) == (-1, -2, -3)
+    assert a * b == 24 and tuple(a * 2) == (2, 4, 6) and tuple(2 * a) == (2, 4, 6) and tuple(a / 2) == (0.5, 1, 1.5)
+    assert tuple(np.float64(2.0) * a) == (2, 4, 6)       # numpy scalar * Vec3 broadcasts over the components
+    assert tuple(a.cross(b)) == (2 * 4 - 3 * 4, 3 * 4 - 1 * 4, 1 * 4 - 2 * 4)
+    assert tuple(a.prod(b)) == (4, 8, 12) and tuple(a.elementwise() * V(1, 0, 1)) == (1, 0, 3)
+    assert abs(V(3, 4, 0).normalize().magnitude() - 1) < 1e-15
+    with pytest.raises(ValueError):
+        V(0).normalize()
+    assert tuple(V(0.6, -0.8, 0).reflect(V(0, 2, 0))) == pytest.approx((0.6, 0.8, 0))
+    assert tuple(V(1, 0, 0).rotate(90, V(0, 0, 1))) == pytest.approx((0, 1, 0))
+    c = V(-1, 2, -3)
+    d = c.absolute()
+    assert tuple(c) == (1, 2, 3) and tuple(d) == (1, 2, 3) and d is not c   # mutates, then copies
+    arr = np.zeros((2, 2, 3))
+    arr[0, 1] += a
+    assert tuple(arr[0, 1]) == (1, 2, 3)
+
+
+def test_shading_helpers_match_upstream_known_answers():
+    for e in h.kat()["shade"]:
+        d, n = core.Vec3(e["d"]), core.Vec3(e["n"])
+        assert raytracing.util.schlick_approximation(-d, n, e["ior"]) == pytest.approx(e["schlick"], rel=1e-13)
+        assert tuple(raytracing.util.refract(d, n, e["eta"])) == pytest.approx(tuple(e["refract"]), rel=1e-12, abs=1e-15)
+        assert tuple(d.reflect(n)) == pytest.approx(tuple(e["reflect"]), rel=1e-12, abs=1e-15)
+    for e in h.kat()["sky"]:
+        assert raytracing.util.vec_to_sky_coords(e["d"]) == pytest.approx(tuple(e["uv"]), abs=1e-15)
+
+
+def test_camera_matches_upstream_known_answers():
+    cam = raytracing.Camera(core.Vec3(0, 0, -2), np.pi / 2, core.Vec3(0))
+    assert cam.d == 1.0000000000000002 and tuple(cam.right) == (1, 0, 0) and tuple(cam.up) == (0, 1, 0)
+    for e in h.kat()["camera_room_1080p"]:
+        ray = cam.get_ray(e["u"], e["v"])
+        assert tuple(ray.direction) == pytest.approx(tuple(e["d"]), abs=1e-15)
+
+
+def test_obj_loader_semantics(tmp_path):
+    p = tmp_path / "two.obj"
+    p.write_text("# c\nmtllib x.mtl\no first\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\ns 0\nf 1/1/1 2/2/1 3/3/1 4/4/1\n"
+                 "o second\nv 0 0 1\nv 1 0 1\nv 0 1 1\nf 5//1 6//1 7//1\n")
+    ms = mesh.Mesh.load_from_obj_file(str(p))
+    assert [m.name for m in ms] == ["first", "second"]
+    assert ms[0].triangles.tolist() == [[0, 1, 2], [0, 2, 3]]          # fan triangulation
+    assert ms[1].triangles.tolist() == [[0, 1, 2]]                     # indices rebased per object
+    assert ms[1].transformed_vertices.tolist() == [[0, 0, 1], [1, 0, 1], [0, 1, 1]]
+    assert tuple(ms[0].bounding_box[0]) == (0, 0, 0) and tuple(ms[0].bounding_box[1]) == (1, 1, 0)
+    assert ms[0].material.ior == 1.45
+
+
+def test_mesh_transform_order():
+    m = mesh.Mesh(core.Material.default_material(), core.Vec3(10, 0, 0), [(1, 0, 0), (0, 1, 0), (0, 0, 1)], [(0, 1, 2)],
+                  scale=core.Vec3(2, 1, 1), rotation=core.Vec3(0, 0, 90))
+    # scale (2,0,0) -> rotate 90 deg about z -> (0,2,0) -> translate
+    assert m.transformed_vertices[0] == pytest.approx((10, 2, 0))
+    m.set_origin(core.Vec3(0))
+    assert m.transformed_vertices[0] == pytest.approx((0, 2, 0))
+    m2 = mesh.Mesh(core.Material.default_material(), core.Vec3(1, 1, 1), [(3, 0, 0), (0, 3, 0), (0, 0, 3)], [(0, 1, 2)])
+    before = m2.transformed_vertices.copy()
+    m2.set_origin_to_center_of_mass()
+    assert tuple(m2.origin) == (2, 2, 2) and np.allclose(m2.vertices.sum(axis=0), 0)
+    assert np.allclose(m2.transformed_vertices, before)   # unscaled, unrotated: shape stays put
+
+
+def test_packer_reproduces_upstream_scene_tables():
+    """Scenes built with THIS package's classes pack to the very tables packed from upstream's
+    objects (fixtures), object order and all - when the asset files are available."""
+    assets = "/root/reference/assets"
+    if not os.path.isdir(assets):
+        pytest.skip("upstream assets are only mounted in the build container")
+    import random
+
+    from raytracing_amd import scenes
+
+    ref = h.packed_scene("room")
+    got = pack_scene(scenes.room(assets))
+    for f in ("obj_kind", "obj_index", "materials", "spheres", "mesh_aabb", "mesh_tri_begin", "tri_verts", "sky_rgb"):
+        assert np.array_equal(getattr(got, f), getattr(ref, f)), f
+    assert got.object_names == ref.object_names and got.sky_scale == 0.4 and got.cam_d == ref.cam_d
+    np.random.seed(7)
+    random.seed(7)
+    ref = h.packed_scene("random_spheres_seed7")
+    got = pack_scene(scenes.random_spheres(assets))
+    assert np.array_equal(got.spheres, ref.spheres) and np.array_equal(got.materials, ref.materials)
+    assert (got.cam_dof_strength, got.cam_dof_dist) == (0.01, 10)
+
+
+def test_packer_duck_typing_and_desc_layout():
+    class O:  # a stand-in for an upstream object: only attributes are read
+        pass
+
+    s = O(); s.material = core.Material.default_material(); s.origin = (1, 2, 3); s.radius = 2.0
+    sc = O(); sc.objects = [s]; sc.camera = raytracing.Camera(core.Vec3(0), 1.0, core.Vec3(0, 0, 1))
+    p = pack_scene(sc)
+    assert p.n_spheres == 1 and p.n_tris == 0 and p.sky_rgb is None
+    d = p.desc()
+    assert d.struct_size == C.sizeof(RtSceneDesc) and d.n_objects == 1 and d.spheres[3] == 2.0
+    with pytest.raises(TypeError):
+        sc.objects = [object.__new__(O)]
+        sc.objects[0].material = s.material
+        pack_scene(sc)
+
+
+def test_packed_scene_roundtrip(tmp_path):
+    ref = h.packed_scene("room")
+    ref.save(str(tmp_path / "s.npz"))
+    back = PackedScene.load(str(tmp_path / "s.npz"))
+    assert np.array_equal(back.tri_verts, ref.tri_verts) and np.array_equal(back.sky_rgb, ref.sky_rgb)
+    assert back.cam_forward == ref.cam_forward and back.object_names == ref.object_names
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads without a GPU and exports exactly what include/raytracing_amd.h declares."""
+    header = open(os.path.join(h.REPO, "include", "raytracing_amd.h")).read()
+    declared = set(re.findall(r"^(?:int|void \*|const char \*)\s*(rt_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert declared == set(rtlib.EXPORTS)
+    handle = rtlib.load_library()
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert handle.rt_abi_version() == 1
+    assert C.sizeof(rtlib.RtRenderParams) == 48
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path fails loudly instead of rendering on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rtlib.BackendError) as e:
+        rtlib.HipBackend(0)
+    assert e.value.status == 4
+    r = raytracing.Renderer()
+    with pytest.raises(rtlib.BackendError):
+        r.init_render(raytracing.RenderSettings(raytracing.Scene(), 8, 8, 1, 1))
+    with pytest.raises(NotImplementedError):
+        r.raytrace(core.Ray(core.Vec3(0), core.Vec3(0, 0, 1)))
+    import raytracing_amd
+
+    for root, _, files in os.walk(os.path.dirname(raytracing_amd.__file__)):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                assert "oracle" not in open(os.path.join(root, f)).read().lower().replace("the cpu oracle", ""), f
+
+
+def test_post_processing_matches_upstream():
+    z, _ = h.load_npz("postproc.npz")
+    pp = post_processing.PostProcessing(exposure=2, brightness=0.02, contrast=1.1, saturation=0.9, gamma=1.2)
+    assert np.allclose(pp.process(z["img"]), z["out"], rtol=1e-12, atol=1e-14)
+    import torch
+
+    t = pp.process(torch.from_numpy(z["img"]))
+    assert np.allclose(t.numpy(), z["out"], rtol=1e-10, atol=1e-12)
+
+
+def test_render_result_views():
+    r = raytracing.RenderResult(4, 3, 2)
+    r.add_to_px(1, 2, core.Vec3(2, 4, 6))
+    r.add_to_px(9, 9, core.Vec3(1))
+    r.rendered_passes = 2
+    r.update_views()
+    assert tuple(r.img_arr[1, 0]) == (1, 2, 3) and tuple(r.img_arr_clipped[1, 0]) == (1, 1, 1)
+    assert r.rendered_pixels == 1 and r.progress == pytest.approx(1 / 12 / 2)
