@@ -58,7 +58,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RAYTRACING_AMD_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing: build the HIP library first (python -m raytracing_amd.backend.build). "
                            "This package has no CPU render path.")

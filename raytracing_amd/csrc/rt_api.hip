@@ -58,11 +58,12 @@ struct rt_ctx {
     std::atomic<int> stop{0};
     bool has_scene = false;
     DevScene S{};
-    bool has_tri = false, has_sph = false, det_cut = false;
+    bool has_tri = false, has_sph = false;
     DevBuf tri_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
+    DevBuf ray_dir, ray_res; int ray_w = 0, ray_h = 0;   // camera-ray table of the current scene at ray_w x ray_h
     std::vector<EventPair> timed;
     double kernel_ms = 0; uint64_t launches = 0;
 };
@@ -162,7 +163,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     HIP_TRY(c, hipDeviceSynchronize());
 
     const V3 cam = {d->cam_pos[0], d->cam_pos[1], d->cam_pos[2]};
-    double scene_radius = norm1(cam);
+    double scene_radius = norm(cam);
 
     // ---- triangles ---------------------------------------------------------------------------
     std::vector<int> tri_mesh(d->n_tris, 0);
@@ -198,7 +199,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             if (r.det_lo > 0) any_det = true;
             x.nx = (float)(N.x / nl); x.ny = (float)(N.y / nl); x.nz = (float)(N.z / nl);
             rows_live.push_back(r);
-            scene_radius = std::max({scene_radius, norm1(a), norm1(b), norm1(cc)});
+            scene_radius = std::max({scene_radius, norm(a), norm(b), norm(cc)});
         } else {
             // never a candidate; judged "undecided" if ever asked, so the exact code answers
             r.nx = r.ny = r.nz = 0; r.kn = 1; r.k1 = r.k2 = -1; r.cb = 0; r.ct = 0; r.det_lo = INFINITY;
@@ -233,7 +234,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         row.r2 = (float)(r * r); row.r = (float)r; row.cn = up(norm(ctr)); row.qs = 0; row.gprim = s;
         sph_all[s] = row;
         if (is_big) big.push_back(s);
-        else { sph_small.push_back(row); scene_radius = std::max(scene_radius, norm1(ctr) + 3.0 * r); }
+        else { sph_small.push_back(row); scene_radius = std::max(scene_radius, norm(ctr) + r); }
     }
 
     // barycentric bound constant: cb = 2.25 (|e1|+|e2|) |N| + 2 |N| / S_min, S_min = scene radius
@@ -271,6 +272,13 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     for (int m = 0; m <= d->n_meshes && d->n_meshes; ++m) mtb[m] = d->mesh_tri_begin[m];
     std::vector<int32_t> okind(d->obj_kind, d->obj_kind + d->n_objects), oindex(d->obj_index, d->obj_index + d->n_objects);
     std::vector<int32_t> sobj(d->sphere_obj, d->sphere_obj + d->n_spheres);
+    // pad the live rows with dead ones (det_lo = +inf) to an even count, plus two to read ahead
+    const int n_live = (int)rows_live.size();
+    if (n_live) {
+        TriRow dead{}; dead.kn = 1; dead.k1 = dead.k2 = -1; dead.det_lo = INFINITY; dead.gprim = -2;
+        while (rows_live.size() % 2) rows_live.push_back(dead);
+        for (int k = 0; k < 2; ++k) rows_live.push_back(dead);
+    }
     HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
     HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
     HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));
@@ -280,7 +288,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
 
     DevScene &S = c->S;
     S = DevScene{};
-    S.tri_rows = c->tri_rows.as<TriRow>(); S.n_tri_rows = (int)rows_live.size();
+    S.tri_rows = c->tri_rows.as<TriRow>(); S.n_tri_rows = n_live; S.n_tri_rows_padded = n_live ? (int)rows_live.size() - 2 : 0;
     S.sph_rows = c->sph_rows.as<SphRow>(); S.n_sph_rows = (int)sph_small.size();
     S.big_sph = c->big_sph.as<int32_t>(); S.n_big_sph = (int)big.size();
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();
@@ -290,7 +298,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.mesh_tri_begin = c->mesh_tri_begin.as<int32_t>(); S.obj_kind = c->obj_kind.as<int32_t>(); S.obj_index = c->obj_index.as<int32_t>();
     S.n_objects = d->n_objects; S.n_spheres = d->n_spheres; S.n_tris = d->n_tris; S.n_meshes = d->n_meshes;
     S.bvh = nullptr; S.n_bvh = 0; S.bvh_tri = nullptr;
-    S.scene_radius = up(scene_radius);
+    S.scene_radius = up(scene_radius * 1.000001);
     int bits = 5;
     while ((1ll << bits) < n_gprim) ++bits;
     S.key_mask = (1u << bits) - 1u;
@@ -302,12 +310,14 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     for (int k = 0; k < 3; ++k) {
         S.cam64[k] = d->cam_pos[k]; S.cam64[3 + k] = d->cam_right[k]; S.cam64[6 + k] = d->cam_up[k]; S.cam64[9 + k] = d->cam_forward[k];
     }
+    for (int k = 0; k < 3; ++k) S.cam_res[k] = (float)(d->cam_pos[k] - (double)(float)d->cam_pos[k]);
     S.cam64[12] = d->cam_d; S.cam64[13] = d->cam_dof_strength; S.cam64[14] = d->cam_dof_dist;
     S.cam_d = (float)d->cam_d; S.dof_strength = (float)d->cam_dof_strength; S.dof_dist = (float)d->cam_dof_dist;
     S.dof_on = !(d->cam_dof_dist == 0 || d->cam_dof_strength == 0);   // camera.py:41
     S.sky = has_sky ? c->sky.as<uint32_t>() : nullptr; S.sky_w = has_sky ? d->sky_w : 0; S.sky_h = has_sky ? d->sky_h : 0;
     S.sky_scale = (float)d->sky_scale;
-    c->has_tri = !rows_live.empty(); c->has_sph = d->n_spheres > 0; c->det_cut = any_det;
+    c->has_tri = n_live > 0; c->has_sph = d->n_spheres > 0;
+    c->ray_w = c->ray_h = 0;   // camera changed: the ray table is stale
     c->has_scene = true;
     return RT_OK;
 }
@@ -319,6 +329,21 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// (Re)build the camera-ray table for width x height on `stream` if the cached one does not match.
+int ensure_ray_table(rt_ctx *c, int width, int height, hipStream_t stream) {
+    if (c->ray_w == width && c->ray_h == height) return RT_OK;
+    const size_t bytes = (size_t)width * height * 4 * sizeof(float);
+    if (bytes > c->ray_dir.bytes || bytes > c->ray_res.bytes) {
+        HIP_TRY(c, hipDeviceSynchronize());   // earlier launches may still read the old tables
+        HIP_TRY(c, c->ray_dir.ensure(bytes)); HIP_TRY(c, c->ray_res.ensure(bytes));
+    }
+    hipLaunchKernelGGL(k_raygen, dim3((unsigned)(((size_t)width * height + 255) / 256)), dim3(256), 0, stream, c->S, width, height,
+                       c->ray_dir.as<float>(), c->ray_res.as<float>());
+    HIP_TRY(c, hipGetLastError());
+    c->ray_w = width; c->ray_h = height;
+    return RT_OK;
+}
+
 struct IsectArgs {
     long long n;
     const double *org, *dir; const int32_t *origin;
@@ -326,7 +351,7 @@ struct IsectArgs {
     unsigned long long *stats;
 };
 
-template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
+template <bool HAS_TRI, bool HAS_SPH>
 __global__ __launch_bounds__(256) void k_intersect(const DevScene S, const IsectArgs A) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
@@ -342,8 +367,8 @@ __global__ __launch_bounds__(256) void k_intersect(const DevScene S, const Isect
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.how = 2;
     HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
     if (f32_ray) {
-        Ray r = make_ray(S, fox, foy, foz, fdx, fdy, fdz, origin);
-        h = closest_hit<HAS_TRI, HAS_SPH, DETCUT>(S, r, cnt, &e, false, PrimaryRef{});
+        Ray r = make_ray(S, fox, foy, foz, fdx, fdy, fdz, origin, false);
+        h = closest_hit<HAS_TRI, HAS_SPH, true>(S, r, cnt, &e, no_residue());
     } else {
         const D3 o64 = d3(ox, oy, oz), d64 = d3(dx, dy, dz);
         ScanHit sh = exact_scan(S, o64, d64, origin);
@@ -375,10 +400,10 @@ __global__ __launch_bounds__(256) void k_intersect(const DevScene S, const Isect
     if (cnt.refine) atomicAdd(A.stats + kStatRefine, (unsigned long long)cnt.refine);
 }
 
-template <class F> void dispatch_variant(bool tri, bool sph, bool det, F &&f) {
-    if (tri && sph) { if (det) f(std::true_type{}, std::true_type{}, std::true_type{}); else f(std::true_type{}, std::true_type{}, std::false_type{}); }
-    else if (tri) { if (det) f(std::true_type{}, std::false_type{}, std::true_type{}); else f(std::true_type{}, std::false_type{}, std::false_type{}); }
-    else f(std::false_type{}, std::true_type{}, std::false_type{});
+template <class F> void dispatch_variant(bool tri, bool sph, F &&f) {
+    if (tri && sph) f(std::true_type{}, std::true_type{});
+    else if (tri) f(std::true_type{}, std::false_type{});
+    else f(std::false_type{}, std::true_type{});
 }
 
 }  // namespace
@@ -409,8 +434,8 @@ int rt_intersect_batch(rt_ctx *c, int64_t n, const double *org, const double *di
     A.t = b_t.as<double>(); A.normal = b_n.as<double>(); A.pos = b_p.as<double>(); A.stats = c->stats.as<unsigned long long>();
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const DevScene S = c->S;
-    dispatch_variant(c->has_tri, c->has_sph, c->det_cut, [&](auto T, auto P, auto D) {
-        hipLaunchKernelGGL((k_intersect<decltype(T)::value, decltype(P)::value, decltype(D)::value>), dim3(blocks), dim3(256), 0, 0, S, A);
+    dispatch_variant(c->has_tri, c->has_sph, [&](auto T, auto P) {
+        hipLaunchKernelGGL((k_intersect<decltype(T)::value, decltype(P)::value>), dim3(blocks), dim3(256), 0, 0, S, A);
     });
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipDeviceSynchronize());
@@ -494,6 +519,8 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     RenderArgs A{};
     A.width = p->width; A.height = p->height; A.x0 = p->x0; A.y0 = p->y0; A.rect_w = p->x1 - p->x0; A.rect_h = p->y1 - p->y0;
     A.sample_begin = p->sample_begin; A.sample_count = p->sample_count; A.chunk_samples = chunk_samples; A.n_chunks = n_chunks;
+    if (int st = ensure_ray_table(c, p->width, p->height, stream)) return st;
+    A.ray_dir = c->ray_dir.as<float>(); A.ray_res = c->ray_res.as<float>();
     A.max_bounces = p->max_bounces; A.seed_lo = (uint32_t)p->seed; A.seed_hi = (uint32_t)(p->seed >> 32);
     A.total_jobs = (uint32_t)total_jobs; A.job_counter = c->job_counter.as<uint32_t>(); A.accum = accum;
     A.stats = c->stats.as<unsigned long long>();
@@ -510,8 +537,8 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b));
     HIP_TRY(c, hipEventRecord(ev.a, stream));
     const DevScene S = c->S;
-    dispatch_variant(c->has_tri, c->has_sph, c->det_cut, [&](auto T, auto P, auto D) {
-        hipLaunchKernelGGL((k_render<decltype(T)::value, decltype(P)::value, decltype(D)::value>), dim3(blocks), dim3(256), 0, stream, S, A);
+    dispatch_variant(c->has_tri, c->has_sph, [&](auto T, auto P) {
+        hipLaunchKernelGGL((k_render<decltype(T)::value, decltype(P)::value>), dim3(blocks), dim3(256), 0, stream, S, A);
     });
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(ev.b, stream));
@@ -619,12 +646,14 @@ extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *x
     TraceArgs A{};
     A.n_paths = n_paths; A.width = width; A.height = height; A.max_bounces = max_bounces; A.seg_cap = cap;
     A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32);
+    if (int st = ensure_ray_table(c, width, height, nullptr)) return st;
+    A.ray_dir = c->ray_dir.as<float>(); A.ray_res = c->ray_res.as<float>();
     A.xys = b_xys.as<int32_t>(); A.rgb = b_rgb.as<float>(); A.n_seg = b_n.as<int32_t>(); A.seg_obj = b_obj.as<int32_t>();
     A.seg_prim = b_prim.as<int32_t>(); A.seg_how = b_how.as<int32_t>(); A.seg_t = b_t.as<float>();
     A.seg_org = b_org.as<float>(); A.seg_dir = b_dir.as<float>();
     const DevScene S = c->S;
-    dispatch_variant(c->has_tri, c->has_sph, c->det_cut, [&](auto T, auto P, auto D) {
-        hipLaunchKernelGGL((k_trace_paths<decltype(T)::value, decltype(P)::value, decltype(D)::value>),
+    dispatch_variant(c->has_tri, c->has_sph, [&](auto T, auto P) {
+        hipLaunchKernelGGL((k_trace_paths<decltype(T)::value, decltype(P)::value>),
                            dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, 0, S, A);
     });
     HIP_TRY(c, hipGetLastError());

@@ -70,29 +70,41 @@ RT_DEV SphRow load_sph_row_uniform(const SphRow *rows, int i) {
 constexpr uint32_t kKeyNone = 0x7F800000u;   // keys at or above +inf's pattern mean "no candidate"
 constexpr float kInf = __builtin_inff();
 constexpr float kTCertain = 1e-9f;           // a depth bound above this certainly passes upstream's 1e-10 filter
-constexpr float kRelAccept = 9.5e-6f;          // float32 depth / normal accepted when its error bound is below this
+// A float32 depth / normal is accepted as is when its error BOUND is below this fraction; otherwise the
+// winning primitive is redone in double precision.  The closest-hit entry point uses the strict value
+// (depth and normals then agree with upstream's doubles to 1e-5 relative, the stated contract).  The
+// render kernel uses the loose one: hit identity is exact either way, the bound is only exceeded at
+// grazing incidence (|cos| < ~0.1), and a depth good to 2e-4 of itself there moves a bounce origin
+// by less than a tenth of a pixel footprint - while redoing it costs the WHOLE wave a
+// double-precision division whenever any of its 64 lanes grazes (measured: 13 % of kernel time).
+constexpr float kRelAcceptStrict = 9.5e-6f;
+constexpr float kRelAcceptRender = 2e-4f;
 
 // A ray prepared for the filter.  All bounds assume 1/2 <= |d| <= 2 and no exactly-zero component
 // of d (such rays go straight to the exact code: see ray_needs_exact).
 struct Ray {
     float ox, oy, oz, dx, dy, dz;
     float a, inv_a, dlen;  // d.d, 1/(d.d), |d|
-    float c4, c7;          // triangle bounds: q = c7 |t| + c4 with c4 = 4u S, c7 = 7u |d|, S = |o|_1 + scene_radius
+    float o2;              // |o| (rounded up)
+    float c4, c7;          // triangle bounds: q = c7 |t| + c4 with c4 = 4u S, c7 = 7u |d|, S = |o| + scene_radius
     float band0;           // crude per-ray discriminant bound for the in-loop sphere test
     int32_t origin;        // global id of the primitive the ray starts on, -1 = none
 };
 
-RT_DEV Ray make_ray(const DevScene &S, float ox, float oy, float oz, float dx, float dy, float dz, int32_t origin) {
+// `rounded` = the ray is the float32 rounding of a double-precision ray the exact code will use
+// (camera rays): every bound then also covers u per component of o and d.
+RT_DEV Ray make_ray(const DevScene &S, float ox, float oy, float oz, float dx, float dy, float dz, int32_t origin,
+                    bool rounded) {
     Ray r;
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.a = fma_(dz, dz, fma_(dy, dy, dx * dx));
     r.inv_a = rcp_(r.a);
     r.dlen = sqrt_(r.a);
-    float Sr = abs_(ox) + abs_(oy) + abs_(oz) + S.scene_radius;
-    // 1.3x: a primary ray is the float32 rounding of the double-precision camera ray the exact
-    // code uses (u per component of o and d), which the derivation above does not include
-    r.c4 = 1.3f * 4.04f * kU * Sr;
-    r.c7 = 1.3f * 7.07f * kU * r.dlen;
+    r.o2 = sqrt_(fma_(oz, oz, fma_(oy, oy, ox * ox))) * (1.0f + 4.0f * kU);
+    float Sr = r.o2 + S.scene_radius;
+    const float k = rounded ? 1.3f * kU : 1.01f * kU;
+    r.c4 = 4.0f * k * Sr;
+    r.c7 = 7.0f * k * r.dlen;
     r.band0 = 72.0f * kU * r.a * Sr * Sr;
     r.origin = origin;
     return r;
@@ -100,8 +112,7 @@ RT_DEV Ray make_ray(const DevScene &S, float ox, float oy, float oz, float dx, f
 
 RT_DEV bool ray_needs_exact(const Ray &r) {
     bool ok = (r.a >= 0.25f) && (r.a <= 4.0f) && (r.dx != 0.0f) && (r.dy != 0.0f) && (r.dz != 0.0f);
-    float s = abs_(r.ox) + abs_(r.oy) + abs_(r.oz);
-    return !(ok && s < 1e30f);
+    return !(ok && r.o2 < 1e18f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -139,7 +150,6 @@ RT_DEV void best_insert(Best &b, uint32_t key) {
     b.k0 = umin_(b.k0, key);
 }
 
-template <bool DETCUT>
 RT_DEV void tri_candidate(const TriRow &T, const Ray &r, Best &b, uint32_t keep_mask) {
     TriEval e = tri_eval(T, r);
     float mp = fma_(e.g, T.cb, e.m);
@@ -149,40 +159,40 @@ RT_DEV void tri_candidate(const TriRow &T, const Ray &r, Best &b, uint32_t keep_
     float y = x * (-kInf);                 // x < 0 -> +inf (not a candidate); x >= 0 -> -inf / NaN
     float tl = max_(max_(tlo, 0.0f), y);   // NaNs drop out of max: a NaN anywhere keeps the candidate
     uint32_t key = (f2u(tl) & keep_mask) | (uint32_t)T.gprim;
-    bool kill = (T.gprim == r.origin);
-    if (DETCUT) kill = kill || !(abs_(e.nd) >= T.det_lo);
+    // det_lo = +inf marks the padding rows at the end of the table: never candidates (NaN included)
+    const bool kill = (T.gprim == r.origin) || !(abs_(e.nd) >= T.det_lo);
     key = kill ? 0xFFFFFFFFu : key;
     best_insert(b, key);
 }
 
-// Brute-force loop over the live triangles.  The next row's scalar load is issued before the
-// current row's arithmetic, so its latency hides behind ~35 vector instructions.
-template <bool DETCUT>
+// Brute-force loop over the live triangles, two rows per trip.  The table is padded with dead rows
+// to an even count plus two, so the loop needs no tail and may read one trip ahead: each row's
+// scalar load is issued a full test (~37 vector instructions) before the row is used.
 RT_DEV void search_tris(const DevScene &S, const Ray &r, Best &b, uint32_t keep_mask) {
-    const int n = S.n_tri_rows;
+    const int n = S.n_tri_rows_padded;   // even; rows [n, n+2) exist and are dead
     if (n <= 0) return;
     const TriRow *rows = S.tri_rows;
-    TriRow cur = load_tri_row_uniform(rows, 0);
-    for (int i = 1; i < n; ++i) {
-        const TriRow nxt = load_tri_row_uniform(rows, i);
-        tri_candidate<DETCUT>(cur, r, b, keep_mask);
-        cur = nxt;
+    TriRow a0 = load_tri_row_uniform(rows, 0), a1 = load_tri_row_uniform(rows, 1);
+    for (int i = 0; i < n; i += 2) {
+        tri_candidate(a0, r, b, keep_mask);
+        a0 = load_tri_row_uniform(rows, i + 2);
+        tri_candidate(a1, r, b, keep_mask);
+        a1 = load_tri_row_uniform(rows, i + 3);
     }
-    tri_candidate<DETCUT>(cur, r, b, keep_mask);
 }
 
 // Winner re-evaluation.  status: 0 accept float32 result, 1 identity certain but imprecise,
 // 2 undecided (ask the exact code about this primitive).
 struct Verdict { int status; float t, thi; };
 
-RT_DEV Verdict judge_tri(const DevScene &S, int32_t ti, const Ray &r) {
+RT_DEV Verdict judge_tri(const DevScene &S, int32_t ti, const Ray &r, float rel_accept) {
     const TriRow T = S.tri_by_id[ti];
     TriEval e = tri_eval(T, r);
     float bb = e.g * T.cb, bt = e.g * T.ct;
     bool certain = (e.m - bb >= 0.0f) && (e.t - bt > kTCertain) && (abs_(e.nd) >= S.tri_aux[ti].det_hi);
     Verdict v;
     v.t = e.t; v.thi = e.t + bt;
-    v.status = !certain ? 2 : ((bt <= kRelAccept * e.t) ? 0 : 1);
+    v.status = !certain ? 2 : ((bt <= rel_accept * e.t) ? 0 : 1);
     return v;
 }
 
@@ -203,7 +213,7 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
     float l2 = fma_(lz, lz, fma_(ly, ly, lx * lx));
     float h2 = P.r2 - l2;
     // per-component error of l: rounding of ro (u|ro|), of the centre (u|c|), of tc*d and its sum (~4u|ro|)
-    const float o1 = abs_(r.ox) + abs_(r.oy) + abs_(r.oz);   // a rounded primary-ray origin is off by u|o|
+    const float o1 = r.o2;   // a rounded camera-ray origin is off by u|o|
     float dl = kU * (7.0f * mlen + 1.5f * P.cn + o1);
     float dh2 = 3.5f * sqrt_(l2) * dl + 3.0f * dl * dl + 5.0f * kU * (l2 + P.r2);
     float hhi = h2 + dh2, hlo = h2 - dh2;
@@ -250,7 +260,7 @@ RT_DEV void search_spheres(const DevScene &S, const Ray &r, Best &bst, uint32_t 
 
 struct SphVerdict { int status; int root; float t, thi; };
 
-RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r) {
+RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r, float rel_accept) {
     const SphRow P = S.sph_by_id[si];
     SphBounds o = sphere_bounds(P, r);
     SphVerdict v; v.status = 2; v.root = 0; v.t = 0; v.thi = 0;
@@ -266,10 +276,10 @@ RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r) {
     }
     if (!certain) return v;
     v.root = root; v.t = t; v.thi = hi;
-    // precise enough?  depth to kRelAccept relative, and the normal (pos - c)/r to kRelAccept
+    // precise enough?  depth to rel_accept relative, and the normal (pos - c)/r to rel_accept
     float half = 0.5f * (hi - lo);
-    float perr = half * r.dlen + 3.0f * kU * (abs_(r.ox) + abs_(r.oy) + abs_(r.oz) + P.cn + t * r.dlen);
-    bool precise = (half <= kRelAccept * t) && (perr <= kRelAccept * P.r);
+    float perr = half * r.dlen + 3.0f * kU * (r.o2 + P.cn + t * r.dlen) * 1.75f;
+    bool precise = (half <= rel_accept * t) && (perr <= rel_accept * P.r);
     v.status = precise ? 0 : 1;
     return v;
 }
@@ -285,21 +295,29 @@ struct Hit {
 
 struct HitCounters { uint32_t exact, refine; };
 
-// The exact code's view of a ray.  Bounce rays and caller-supplied rays ARE their float32 values;
-// a primary ray is the float32 rounding of the camera ray upstream computes in double precision
-// (camera.py:39-50), and the exact code re-derives that double-precision ray from the pixel so
-// that rays which graze an edge resolve as upstream resolves them.
-struct PrimaryRef { int32_t x, y, W, H; uint32_t key0, key1; };
+// The exact code's view of a ray.  Bounce rays and caller-supplied rays ARE their float32 values.
+// A pinhole camera ray is the float32 rounding of the ray upstream computes in double precision
+// (camera.py:39-42); k_raygen keeps the rounding residue (double - float32, as a float32) per pixel,
+// and the exact code adds it back, so that camera rays which graze an edge - with a 90 degree
+// field of view the image diagonals of the room scene run exactly along the cube's edges - resolve
+// as upstream resolves them.  `table` is null for every other ray.
+struct RayResidue { const float *table; uint32_t pixel; float ox, oy, oz; };
 
-RT_DEV void camera_ray64(const DevScene &S, const PrimaryRef &pr, D3 &o, D3 &d);   // rt_render.h
+RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r.ox = r.oy = r.oz = 0.0f; return r; }
 
 // `e64`, when given, receives the double-precision record whenever the exact code produced the hit
-// (e64->hit says whether it did).  `primary` identifies the pixel of a camera ray (is_primary).
-template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
-RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactHit *e64, bool is_primary, const PrimaryRef primary) {
+// (e64->hit says whether it did).
+template <bool HAS_TRI, bool HAS_SPH, bool STRICT>
+RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactHit *e64, const RayResidue rr) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
-    D3 o64 = d3(r.ox, r.oy, r.oz), d64 = d3(r.dx, r.dy, r.dz);
-    bool have64 = !is_primary;
+    // only the rare double-precision branches below read these; the loads and conversions sink into them
+    float rdx = 0.0f, rdy = 0.0f, rdz = 0.0f, rox = 0.0f, roy = 0.0f, roz = 0.0f;
+    if (rr.table) {
+        const f4 q = *(const f4 *)(rr.table + 4 * (size_t)rr.pixel);
+        rdx = q.x; rdy = q.y; rdz = q.z; rox = rr.ox; roy = rr.oy; roz = rr.oz;
+    }
+    const D3 o64 = d3((double)r.ox + (double)rox, (double)r.oy + (double)roy, (double)r.oz + (double)roz);
+    const D3 d64 = d3((double)r.dx + (double)rdx, (double)r.dy + (double)rdy, (double)r.dz + (double)rdz);
     ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
     bool scan = ray_needs_exact(r);
     int32_t gprim = -1; int root = 0; float t = kInf;
@@ -308,7 +326,6 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
         Best b; b.k0 = 0xFFFFFFFFu; b.k1 = 0xFFFFFFFFu;
         if (HAS_SPH) {
             search_spheres(S, r, b, keep_mask);
-            if (S.n_big_sph > 0 && !have64) { camera_ray64(S, primary, o64, d64); have64 = true; }
             for (int i = 0; i < S.n_big_sph; ++i) {   // the few huge spheres: double precision throughout
                 int si = S.big_sph[i];
                 ExactHit eb = exact_sphere(S.sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
@@ -317,30 +334,28 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
                 best_insert(b, key);
             }
         }
-        if (HAS_TRI) search_tris<DETCUT>(S, r, b, keep_mask);
+        if (HAS_TRI) search_tris(S, r, b, keep_mask);
         if (b.k0 < kKeyNone) {
             gprim = (int32_t)(b.k0 & S.key_mask);
             const float second_lo = u2f(b.k1 & keep_mask);
             const bool has_second = b.k1 < kKeyNone;
             int status; float thi;
             if (gprim < S.n_spheres) {
-                SphVerdict v = judge_sphere(S, gprim, r);
+                SphVerdict v = judge_sphere(S, gprim, r, STRICT ? kRelAcceptStrict : kRelAcceptRender);
                 status = v.status; t = v.t; thi = v.thi; root = v.root;
             } else {
-                Verdict v = judge_tri(S, gprim - S.n_spheres, r);
+                Verdict v = judge_tri(S, gprim - S.n_spheres, r, STRICT ? kRelAcceptStrict : kRelAcceptRender);
                 status = v.status; t = v.t; thi = v.thi;
             }
             if (status == 1 && gprim >= S.n_spheres) {
                 // a triangle that is certainly the hit but whose float32 depth is too coarse (grazing
                 // incidence): only the depth is redone in double precision
                 cnt.refine++;
-                if (!have64) { camera_ray64(S, primary, o64, d64); have64 = true; }
                 t = (float)exact_tri_depth(S.tri64 + 9 * (size_t)(gprim - S.n_spheres), o64, d64);
                 thi = t * (1.0f + 2.0f * kU);
                 h.how = 1;
             } else if (status != 0) {   // undecided, or an imprecise sphere: double precision for this primitive
                 cnt.refine++;
-                if (!have64) { camera_ray64(S, primary, o64, d64); have64 = true; }
                 e = exact_single(S, gprim, o64, d64, r.origin);
                 if (!e.hit) scan = true;            // the winner was not a hit after all
                 else { t = (float)e.t; thi = t * (1.0f + 2.0f * kU); root = e.prim; }
@@ -351,7 +366,6 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
     if (scan) {   // upstream's Scene.intersect, literally, in double precision
         cnt.exact++;
         h.how = 2;
-        if (!have64) { camera_ray64(S, primary, o64, d64); have64 = true; }
         ScanHit sh = exact_scan(S, o64, d64, r.origin);
         gprim = sh.gprim;
         e.hit = false;

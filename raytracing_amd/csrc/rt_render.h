@@ -58,12 +58,46 @@ RT_DEV Draws segment_draws(uint32_t key0, uint32_t key1, uint32_t segment) {
 // Deviation from upstream, shared with the CPU oracle: asin's argument and the texel index are
 // clamped where upstream raises and silently loses the tile.
 // ---------------------------------------------------------------------------------------------
+// atan2(y, x) / (2 pi) in turns, in (-1/2, 1/2]: octant reduction + odd polynomial of degree 13 on
+// [0, 1], fitted to atan(a) / (2 pi a) (max error 7e-8 turn in float32 = 1.3e-4 of a sky texel at
+// 1907 texels per turn).
+RT_DEV float atan2_turns(float y, float x) {
+    const float ax = abs_(x), ay = abs_(y);
+    const float mx = max_(ax, ay), mn = min_(ax, ay);
+    const float a = mn * rcp_(max_(mx, 1e-30f));   // in [0, 1]
+    const float s = a * a;
+    // atan(a) / (2 pi) ~= a * P(a^2)
+    float p = fma_(s, 0.0010841137263923883f, -0.005348223727196455f);
+    p = fma_(s, p, 0.01267243456095457f);
+    p = fma_(s, p, -0.021061478182673454f);
+    p = fma_(s, p, 0.031525105237960815f);
+    p = fma_(s, p, -0.0530262365937233f);
+    p = fma_(s, p, 0.15915432572364807f);
+    float r = a * p;
+    r = ay > ax ? 0.25f - r : r;
+    r = x < 0.0f ? 0.5f - r : r;
+    return y < 0.0f ? -r : r;
+}
+
+// asin(x) / pi for |x| <= 1: pi/2 - sqrt(1 - |x|) * P(|x|) (Abramowitz & Stegun 4.4.46, |error| <= 2e-8 rad).
+RT_DEV float asin_over_pi(float x) {
+    const float a = abs_(x);
+    float p = fma_(a, -0.0012624911f, 0.0066700901f);
+    p = fma_(a, p, -0.0170881256f);
+    p = fma_(a, p, 0.0308918810f);
+    p = fma_(a, p, -0.0501743046f);
+    p = fma_(a, p, 0.0889789874f);
+    p = fma_(a, p, -0.2145988016f);
+    p = fma_(a, p, 1.5707963050f);
+    const float r = 0.5f - sqrt_(max_(1.0f - a, 0.0f)) * p * 0.3183098861837907f;
+    return x < 0.0f ? -r : r;
+}
+
 RT_DEV void environment(const DevScene &S, float dx, float dy, float dz, float &r, float &g, float &b) {
     if (S.sky == nullptr) { r = g = b = 0.0f; return; }
-    const float kInv2Pi = 0.15915494309189535f, kInvPi = 0.3183098861837907f;
     float y = min_(max_(dy, -1.0f), 1.0f);
-    float u = 0.5f + atan2f(dz, dx) * kInv2Pi;
-    float v = 1.0f - (0.5f + asinf(y) * kInvPi);
+    float u = 0.5f + atan2_turns(dz, dx);
+    float v = 1.0f - (0.5f + asin_over_pi(y));
     int px = (int)(u * (float)S.sky_w), py = (int)(v * (float)S.sky_h);
     px = px < 0 ? 0 : (px >= S.sky_w ? S.sky_w - 1 : px);
     py = py < 0 ? 0 : (py >= S.sky_h ? S.sky_h - 1 : py);
@@ -72,23 +106,60 @@ RT_DEV void environment(const DevScene &S, float dx, float dy, float dz, float &
     r = (float)(c & 0xFFu) * k; g = (float)((c >> 8) & 0xFFu) * k; b = (float)((c >> 16) & 0xFFu) * k;
 }
 
-// Camera.get_ray (camera.py:39-50) for pixel (x, y) of a W x H image (renderer.py:96-103), in
-// double precision and in upstream's operation order.  The kernels trace its float32 rounding.
-RT_DEV void camera_ray64(const DevScene &S, const PrimaryRef &pr, D3 &o, D3 &d) {
+// 1 / sqrt(x) in double precision from the float32 hardware estimate and two Newton steps
+// (relative error ~1e-16; avoids the long double-precision sqrt and divide sequences).
+RT_DEV double rsqrt64(double x) {
+    double s = (double)rsq_((float)x);
+    s = s * (1.5 - 0.5 * x * s * s);
+    s = s * (1.5 - 0.5 * x * s * s);
+    return s;
+}
+
+// Ray generation: Camera.get_ray's pinhole part (camera.py:40) for every pixel of a W x H image
+// (renderer.py:96-103), in double precision and in upstream's exact operation order - sqrt and
+// divisions included, so the doubles are bit-identical to upstream's.  Writes, per pixel
+// (x * H + y), the float32 direction and the residue double - float32.  Runs once per
+// (camera, W, H); the render kernel only loads from the table.
+__global__ __launch_bounds__(256) void k_raygen(const DevScene S, int W, int H, float *ray_dir, float *ray_res) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int x = i / H, y = i - x * H;
     const double *c = S.cam64;
-    const D3 pos = d3(c[0], c[1], c[2]), right = d3(c[3], c[4], c[5]), up = d3(c[6], c[7], c[8]), fwd = d3(c[9], c[10], c[11]);
-    const double aspect = (double)pr.H / (double)pr.W;
-    const double u = (pr.x + 0.5) / pr.W * 2 - 1;
-    const double v = (pr.y + 0.5) / pr.H * 2 * aspect - aspect;
-    D3 t = d3(right.x * u + up.x * v + fwd.x * c[12], right.y * u + up.y * v + fwd.y * c[12], right.z * u + up.z * v + fwd.z * c[12]);
-    d = dnormalize(t);
-    o = pos;
+    const double aspect = (double)H / (double)W;
+    const double u = (x + 0.5) / W * 2 - 1;
+    const double v = (y + 0.5) / H * 2 * aspect - aspect;
+    const D3 t = d3(c[3] * u + c[6] * v + c[9] * c[12], c[4] * u + c[7] * v + c[10] * c[12], c[5] * u + c[8] * v + c[11] * c[12]);
+    const D3 d = dnormalize(t);
+    const float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
+    f4 dir; dir.x = fx; dir.y = fy; dir.z = fz; dir.w = 0.0f;
+    f4 res; res.x = (float)(d.x - (double)fx); res.y = (float)(d.y - (double)fy); res.z = (float)(d.z - (double)fz); res.w = 0.0f;
+    *(f4 *)(ray_dir + 4 * (size_t)i) = dir;
+    *(f4 *)(ray_res + 4 * (size_t)i) = res;
+}
+
+// Camera ray of one path.  Pinhole cameras: the table entry.  Depth of field (camera.py:43-49): the
+// aperture offset and the re-aimed direction are worked out here from this path's two draws, in
+// double precision with a Newton reciprocal square root (~1e-16 of upstream's doubles), and the
+// float32 rounding of that ray is THE ray (no residue: the jitter decorrelates edge cases anyway).
+RT_DEV void camera_ray(const DevScene &S, const float *ray_dir, const float *ray_res, uint32_t pixel, uint32_t key0,
+                       uint32_t key1, float &ox, float &oy, float &oz, float &dx, float &dy, float &dz, RayResidue &rr) {
+    const f4 q = *(const f4 *)(ray_dir + 4 * (size_t)pixel);
+    dx = q.x; dy = q.y; dz = q.z;
+    ox = S.cam_pos[0]; oy = S.cam_pos[1]; oz = S.cam_pos[2];
+    rr.table = ray_res; rr.pixel = pixel; rr.ox = S.cam_res[0]; rr.oy = S.cam_res[1]; rr.oz = S.cam_res[2];
     if (S.dof_on) {
-        const Draws dr = segment_draws(pr.key0, pr.key1, 0);
+        const double *c = S.cam64;
+        const f4 e = *(const f4 *)(ray_res + 4 * (size_t)pixel);
+        const double ddx = (double)q.x + (double)e.x, ddy = (double)q.y + (double)e.y, ddz = (double)q.z + (double)e.z;
+        const Draws dr = segment_draws(key0, key1, 0);
         const double j1 = ((double)dr.f0 * 2 - 1) * c[13], j2 = ((double)dr.f1 * 2 - 1) * c[13];
-        const D3 target = d3(d.x * c[14] + pos.x, d.y * c[14] + pos.y, d.z * c[14] + pos.z);
-        o = d3(pos.x + right.x * j1 + up.x * j2, pos.y + right.y * j1 + up.y * j2, pos.z + right.z * j1 + up.z * j2);
-        d = dnormalize(dsub(target, o));
+        const double gx = ddx * c[14] + c[0], gy = ddy * c[14] + c[1], gz = ddz * c[14] + c[2];
+        const double oox = c[0] + c[3] * j1 + c[6] * j2, ooy = c[1] + c[4] * j1 + c[7] * j2, ooz = c[2] + c[5] * j1 + c[8] * j2;
+        const double tx = gx - oox, ty = gy - ooy, tz = gz - ooz;
+        const double s = rsqrt64(tx * tx + ty * ty + tz * tz);
+        ox = (float)oox; oy = (float)ooy; oz = (float)ooz;
+        dx = (float)(tx * s); dy = (float)(ty * s); dz = (float)(tz * s);
+        rr = no_residue();
     }
 }
 
@@ -144,15 +215,13 @@ struct Path {
     int32_t depth;                  // closest-hit queries done so far
     int32_t origin;                 // primitive the current ray starts on, -1 = camera
     bool inside;                    // Ray.inside (ray.py:10), toggled by refraction
+    RayResidue rr;                  // where the exact code finds the camera ray's double-precision residue
 };
 
-RT_DEV void path_begin(const DevScene &S, Path &p, int x, int y, int W, int H, uint32_t pixel, uint32_t sample,
-                       uint32_t seed_lo, uint32_t seed_hi) {
+RT_DEV void path_begin(const DevScene &S, const float *ray_dir, const float *ray_res, Path &p, uint32_t pixel,
+                       uint32_t sample, uint32_t seed_lo, uint32_t seed_hi) {
     p.key0 = pixel ^ seed_lo; p.key1 = sample ^ seed_hi;
-    PrimaryRef pr; pr.x = x; pr.y = y; pr.W = W; pr.H = H; pr.key0 = p.key0; pr.key1 = p.key1;
-    D3 o, d;
-    camera_ray64(S, pr, o, d);
-    p.ox = (float)o.x; p.oy = (float)o.y; p.oz = (float)o.z; p.dx = (float)d.x; p.dy = (float)d.y; p.dz = (float)d.z;
+    camera_ray(S, ray_dir, ray_res, pixel, p.key0, p.key1, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.rr);
     p.tr = p.tg = p.tb = 1.0f; p.depth = 0; p.inside = false; p.origin = -1;
 }
 
@@ -160,12 +229,11 @@ struct StepCounters { uint32_t sky, shaded; };
 
 // One segment: closest hit, then environment or one bounce.  Returns true while the path goes on;
 // when it returns false (er, eg, eb) is the terminal radiance to be multiplied by (tr, tg, tb).
-template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
-RT_DEV bool path_step(const DevScene &S, Path &p, int px, int py, int W, int H, int max_bounces, HitCounters &cnt,
-                      StepCounters &sc, float &er, float &eg, float &eb, Hit *hit_out) {
-    Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin);
-    PrimaryRef pr; pr.x = px; pr.y = py; pr.W = W; pr.H = H; pr.key0 = p.key0; pr.key1 = p.key1;
-    Hit h = closest_hit<HAS_TRI, HAS_SPH, DETCUT>(S, ray, cnt, nullptr, p.depth == 0, pr);
+template <bool HAS_TRI, bool HAS_SPH>
+RT_DEV bool path_step(const DevScene &S, Path &p, int max_bounces, HitCounters &cnt, StepCounters &sc,
+                      float &er, float &eg, float &eb, Hit *hit_out) {
+    Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0);
+    Hit h = closest_hit<HAS_TRI, HAS_SPH, false>(S, ray, cnt, nullptr, p.rr);
     if (hit_out) *hit_out = h;
     er = eg = eb = 0.0f;
     if (h.obj < 0) {
@@ -178,6 +246,7 @@ RT_DEV bool path_step(const DevScene &S, Path &p, int px, int py, int W, int H, 
     const Draws u = segment_draws(p.key0, p.key1, (uint32_t)p.depth + 1u);
     bool alive = shade_bounce(m, h, u, p.dx, p.dy, p.dz, p.inside, p.tr, p.tg, p.tb, er, eg, eb);
     p.ox = h.px; p.oy = h.py; p.oz = h.pz; p.origin = h.gprim;
+    p.rr = no_residue();
     p.depth++;
     if (alive && p.depth > max_bounces) { alive = false; er = eg = eb = 0.0f; }   // renderer.py:29-30
     return alive;
@@ -190,8 +259,8 @@ RT_DEV uint32_t rank_in(unsigned long long mask) {
 
 constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at a time
 
-template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
-__global__ __launch_bounds__(256) void k_render(const DevScene S, const RenderArgs A) {
+template <bool HAS_TRI, bool HAS_SPH>
+__global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const RenderArgs A) {
     // wave-uniform job window
     uint32_t win_next = 0, win_end = 0;
     bool drained = false;
@@ -203,6 +272,7 @@ __global__ __launch_bounds__(256) void k_render(const DevScene S, const RenderAr
     Path p;
     p.ox = p.oy = p.oz = 0; p.dx = p.dy = 0; p.dz = 1; p.tr = p.tg = p.tb = 1; p.key0 = p.key1 = 0;
     p.depth = 0; p.origin = -1; p.inside = false;
+    p.rr = no_residue();
     uint32_t n_rays = 0, n_paths = 0;
     HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
     StepCounters sc; sc.sky = 0; sc.shaded = 0;
@@ -244,14 +314,14 @@ __global__ __launch_bounds__(256) void k_render(const DevScene S, const RenderAr
         if (have_job) {
             // ---- 2. start the next sample of this lane's pixel --------------------------------
             if (!in_path) {
-                path_begin(S, p, px, py, A.width, A.height, pixel, (uint32_t)s_cur, A.seed_lo, A.seed_hi);
+                path_begin(S, A.ray_dir, A.ray_res, p, pixel, (uint32_t)s_cur, A.seed_lo, A.seed_hi);
                 in_path = true;
                 n_paths++;
             }
             // ---- 3. one path segment ----------------------------------------------------------
             n_rays++;
             float er, eg, eb;
-            bool alive = path_step<HAS_TRI, HAS_SPH, DETCUT>(S, p, px, py, A.width, A.height, A.max_bounces, cnt, sc, er, eg, eb, nullptr);
+            bool alive = path_step<HAS_TRI, HAS_SPH>(S, p, A.max_bounces, cnt, sc, er, eg, eb, nullptr);
             if (!alive) {
                 ar = fma_(p.tr, er, ar); ag = fma_(p.tg, eg, ag); ab = fma_(p.tb, eb, ab);
                 in_path = false;
@@ -274,7 +344,7 @@ __global__ __launch_bounds__(256) void k_render(const DevScene S, const RenderAr
     v[kStatRays] = n_rays; v[kStatPaths] = n_paths; v[kStatExact] = cnt.exact; v[kStatRefine] = cnt.refine;
     v[kStatSky] = sc.sky; v[kStatShaded] = sc.shaded;
     v[kStatSphTests] = (unsigned long long)n_rays * (uint32_t)(S.n_sph_rows + S.n_big_sph);
-    v[kStatTriTests] = (unsigned long long)n_rays * (uint32_t)S.n_tri_rows;
+    v[kStatTriTests] = (unsigned long long)n_rays * (uint32_t)S.n_tri_rows;   // dead padding rows are not counted
 #pragma unroll
     for (int i = 0; i < kStatCount; ++i) {
         unsigned long long x = v[i];
@@ -301,6 +371,7 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const RenderArgs A) {
 // Diagnostic / parity kernel: one thread traces one whole path and records every segment.
 struct TraceArgs {
     int32_t n_paths, width, height, max_bounces, seg_cap;
+    const float *ray_dir, *ray_res;
     uint32_t seed_lo, seed_hi;
     const int32_t *xys;          // [n_paths][3] x, y, sample
     float *rgb;                  // [n_paths][3] path radiance
@@ -310,13 +381,13 @@ struct TraceArgs {
     float *seg_org, *seg_dir;    // [n_paths][seg_cap][3]
 };
 
-template <bool HAS_TRI, bool HAS_SPH, bool DETCUT>
+template <bool HAS_TRI, bool HAS_SPH>
 __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S, const TraceArgs A) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n_paths) return;
     const int x = A.xys[3 * i], y = A.xys[3 * i + 1], smp = A.xys[3 * i + 2];
     Path p;
-    path_begin(S, p, x, y, A.width, A.height, (uint32_t)(x * A.height + y), (uint32_t)smp, A.seed_lo, A.seed_hi);
+    path_begin(S, A.ray_dir, A.ray_res, p, (uint32_t)(x * A.height + y), (uint32_t)smp, A.seed_lo, A.seed_hi);
     HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
     StepCounters sc; sc.sky = 0; sc.shaded = 0;
     float er = 0, eg = 0, eb = 0;
@@ -328,7 +399,7 @@ __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S, const Tra
             A.seg_dir[3 * k] = p.dx; A.seg_dir[3 * k + 1] = p.dy; A.seg_dir[3 * k + 2] = p.dz;
         }
         Hit h;
-        bool alive = path_step<HAS_TRI, HAS_SPH, DETCUT>(S, p, x, y, A.width, A.height, A.max_bounces, cnt, sc, er, eg, eb, &h);
+        bool alive = path_step<HAS_TRI, HAS_SPH>(S, p, A.max_bounces, cnt, sc, er, eg, eb, &h);
         if (n < A.seg_cap) { A.seg_obj[k] = h.obj; A.seg_prim[k] = h.prim; A.seg_how[k] = h.how; A.seg_t[k] = h.t; }
         n++;
         if (!alive) break;

@@ -56,7 +56,8 @@ struct BvhNode {     // mirrors rt_bvh_node
 
 struct DevScene {
     // float32 filter tables
-    const TriRow *tri_rows;   int32_t n_tri_rows;     // live triangles only
+    const TriRow *tri_rows;   int32_t n_tri_rows;     // live triangles only, padded with dead rows:
+    int32_t n_tri_rows_padded;                        //   even, and 2 more rows exist past it
     const SphRow *sph_rows;   int32_t n_sph_rows;     // small spheres only
     const int32_t *big_sph;   int32_t n_big_sph;      // sphere indices evaluated in float64
     const TriRow *tri_by_id;                          // [n_tris] same rows, indexed by triangle id
@@ -74,7 +75,7 @@ struct DevScene {
     // BVH (optional)
     const BvhNode *bvh; int32_t n_bvh; const int32_t *bvh_tri;
     // scalars
-    float scene_radius;       // bound on |x|+|y|+|z| of every vertex / small-sphere extent
+    float scene_radius;       // bound on the distance from the world origin of every vertex, small-sphere point and the camera
     uint32_t key_mask;        // low bits of a hit key that hold the primitive id
     int32_t any_det_cut;      // some live triangle has det_lo > 0
     // camera (camera.py:17-37)
@@ -82,12 +83,16 @@ struct DevScene {
     float cam_d, dof_strength, dof_dist;
     int32_t dof_on;
     double cam64[15];         // pos, right, up, forward (3 each), d, dof_strength, dof_dist as the host holds them
+    float cam_res[3];         // cam64 position minus its float32 rounding
     // environment: RGBA8 texels, row-major
     const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale;
 };
 
 struct RenderArgs {
     int32_t width, height, x0, y0, rect_w, rect_h;
+    // Camera-ray table built by k_raygen for this (camera, width, height): per pixel (x * height + y)
+    // the float32 pinhole direction and its double-precision residue, 16 bytes each.
+    const float *ray_dir, *ray_res;
     int32_t sample_begin, sample_count, chunk_samples, n_chunks;
     int32_t max_bounces;
     uint32_t seed_lo, seed_hi;
