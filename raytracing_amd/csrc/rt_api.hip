@@ -60,7 +60,7 @@ struct rt_ctx {
     DevScene S{};
     bool has_tri = false, has_sph = false;
     DevBuf tri_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
-    DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri;
+    DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
     DevBuf ray_dir, ray_res; int ray_w = 0, ray_h = 0;   // camera-ray table of the current scene at ray_w x ray_h
@@ -89,6 +89,15 @@ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x
 double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 double norm(V3 a) { return std::sqrt(dot(a, a)); }
 double norm1(V3 a) { return std::fabs(a.x) + std::fabs(a.y) + std::fabs(a.z); }
+
+FastDiv make_fast_div(uint32_t d) {
+    FastDiv f{}; f.d = d;
+    uint32_t L = 0;
+    while ((1ull << L) < d) ++L;                       // ceil(log2 d)
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+    f.sh1 = L < 1 ? L : 1; f.sh2 = L > 0 ? L - 1 : 0;
+    return f;
+}
 
 // Largest float not above / smallest float not below a positive double (bounds must stay bounds).
 float up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; }
@@ -294,25 +303,23 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();
     S.sph_by_id = c->sph_by_id.as<SphRow>(); S.sph_obj = c->sph_obj.as<int32_t>();
     S.materials = c->materials.as<MatRow>();
-    S.tri64 = c->tri64.as<double>(); S.sph64 = c->sph64.as<double>(); S.aabb64 = c->aabb64.as<double>();
-    S.mesh_tri_begin = c->mesh_tri_begin.as<int32_t>(); S.obj_kind = c->obj_kind.as<int32_t>(); S.obj_index = c->obj_index.as<int32_t>();
-    S.n_objects = d->n_objects; S.n_spheres = d->n_spheres; S.n_tris = d->n_tris; S.n_meshes = d->n_meshes;
-    S.bvh = nullptr; S.n_bvh = 0; S.bvh_tri = nullptr;
+    ColdScene cold{};
+    cold.tri64 = c->tri64.as<double>(); cold.sph64 = c->sph64.as<double>(); cold.aabb64 = c->aabb64.as<double>();
+    cold.mesh_tri_begin = c->mesh_tri_begin.as<int32_t>(); cold.obj_kind = c->obj_kind.as<int32_t>(); cold.obj_index = c->obj_index.as<int32_t>();
+    cold.n_objects = d->n_objects; cold.n_tris = d->n_tris; cold.n_meshes = d->n_meshes;
+    for (int k = 0; k < 3; ++k) {
+        cold.cam64[k] = d->cam_pos[k]; cold.cam64[3 + k] = d->cam_right[k]; cold.cam64[6 + k] = d->cam_up[k]; cold.cam64[9 + k] = d->cam_forward[k];
+        S.cam_pos[k] = (float)d->cam_pos[k];
+        S.cam_res[k] = (float)(d->cam_pos[k] - (double)(float)d->cam_pos[k]);
+    }
+    cold.cam64[12] = d->cam_d; cold.cam64[13] = d->cam_dof_strength; cold.cam64[14] = d->cam_dof_dist;
+    HIP_TRY(c, c->cold.upload(std::vector<ColdScene>{cold}));
+    S.cold = c->cold.as<ColdScene>();
+    S.n_spheres = d->n_spheres;
     S.scene_radius = up(scene_radius * 1.000001);
     int bits = 5;
     while ((1ll << bits) < n_gprim) ++bits;
     S.key_mask = (1u << bits) - 1u;
-    S.any_det_cut = any_det;
-    for (int k = 0; k < 3; ++k) {
-        S.cam_pos[k] = (float)d->cam_pos[k]; S.cam_right[k] = (float)d->cam_right[k];
-        S.cam_up[k] = (float)d->cam_up[k]; S.cam_fwd[k] = (float)d->cam_forward[k];
-    }
-    for (int k = 0; k < 3; ++k) {
-        S.cam64[k] = d->cam_pos[k]; S.cam64[3 + k] = d->cam_right[k]; S.cam64[6 + k] = d->cam_up[k]; S.cam64[9 + k] = d->cam_forward[k];
-    }
-    for (int k = 0; k < 3; ++k) S.cam_res[k] = (float)(d->cam_pos[k] - (double)(float)d->cam_pos[k]);
-    S.cam64[12] = d->cam_d; S.cam64[13] = d->cam_dof_strength; S.cam64[14] = d->cam_dof_dist;
-    S.cam_d = (float)d->cam_d; S.dof_strength = (float)d->cam_dof_strength; S.dof_dist = (float)d->cam_dof_dist;
     S.dof_on = !(d->cam_dof_dist == 0 || d->cam_dof_strength == 0);   // camera.py:41
     S.sky = has_sky ? c->sky.as<uint32_t>() : nullptr; S.sky_w = has_sky ? d->sky_w : 0; S.sky_h = has_sky ? d->sky_h : 0;
     S.sky_scale = (float)d->sky_scale;
@@ -522,7 +529,8 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     if (int st = ensure_ray_table(c, p->width, p->height, stream)) return st;
     A.ray_dir = c->ray_dir.as<float>(); A.ray_res = c->ray_res.as<float>();
     A.max_bounces = p->max_bounces; A.seed_lo = (uint32_t)p->seed; A.seed_hi = (uint32_t)(p->seed >> 32);
-    A.total_jobs = (uint32_t)total_jobs; A.job_counter = c->job_counter.as<uint32_t>(); A.accum = accum;
+    A.total_jobs = (uint32_t)total_jobs;
+    A.div_rect_px = make_fast_div((uint32_t)rect_px); A.div_rect_h = make_fast_div((uint32_t)A.rect_h); A.job_counter = c->job_counter.as<uint32_t>(); A.accum = accum;
     A.stats = c->stats.as<unsigned long long>();
     if (n_chunks > 1) {
         // grows only; a larger request first drains work that may still read the old buffer

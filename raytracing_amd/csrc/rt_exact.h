@@ -112,30 +112,32 @@ struct ScanHit { int32_t gprim; double t; };   // gprim < 0: miss
 
 // One primitive by global id, with its mesh's bounding-box gate.
 RT_DEV ExactHit exact_single(const DevScene &S, int32_t gprim, D3 o, D3 d, int32_t origin) {
-    if (gprim < S.n_spheres) return exact_sphere(S.sph64 + 4 * (size_t)gprim, o, d, gprim == origin);
+    const ColdScene &C = *S.cold;
+    if (gprim < S.n_spheres) return exact_sphere(C.sph64 + 4 * (size_t)gprim, o, d, gprim == origin);
     int32_t ti = gprim - S.n_spheres;
     ExactHit miss; miss.hit = false; miss.prim = 0; miss.t = 0; miss.n = d3(0, 0, 0); miss.pos = miss.n;
     if (gprim == origin) return miss;
-    if (!exact_aabb(S.aabb64 + 6 * (size_t)S.tri_aux[ti].mesh, o, d)) return miss;
-    return exact_tri(S.tri64 + 9 * (size_t)ti, o, d);
+    if (!exact_aabb(C.aabb64 + 6 * (size_t)S.tri_aux[ti].mesh, o, d)) return miss;
+    return exact_tri(C.tri64 + 9 * (size_t)ti, o, d);
 }
 
 // Scene.intersect(ray)[0]: first minimum of depth in object order, then per-object hit order.
 // Returns the identity and depth only; the caller re-evaluates the winner for position / normal
 // (same arithmetic, so the same depth).
 RT_DEV ScanHit exact_scan(const DevScene &S, D3 o, D3 d, int32_t origin) {
+    const ColdScene &C = *S.cold;
     ScanHit best; best.gprim = -1; best.t = __builtin_inf();
-    for (int oi = 0; oi < S.n_objects; ++oi) {
-        int idx = S.obj_index[oi];
-        if (S.obj_kind[oi] == 0) {
-            ExactHit h = exact_sphere(S.sph64 + 4 * (size_t)idx, o, d, idx == origin, false);
+    for (int oi = 0; oi < C.n_objects; ++oi) {
+        int idx = C.obj_index[oi];
+        if (C.obj_kind[oi] == 0) {
+            ExactHit h = exact_sphere(C.sph64 + 4 * (size_t)idx, o, d, idx == origin, false);
             if (h.hit && h.t < best.t) { best.gprim = idx; best.t = h.t; }
         } else {
-            if (!exact_aabb(S.aabb64 + 6 * (size_t)idx, o, d)) continue;
-            int t0 = S.mesh_tri_begin[idx], t1 = S.mesh_tri_begin[idx + 1];
+            if (!exact_aabb(C.aabb64 + 6 * (size_t)idx, o, d)) continue;
+            int t0 = C.mesh_tri_begin[idx], t1 = C.mesh_tri_begin[idx + 1];
             for (int ti = t0; ti < t1; ++ti) {
                 if (S.n_spheres + ti == origin) continue;
-                ExactHit h = exact_tri(S.tri64 + 9 * (size_t)ti, o, d, false);
+                ExactHit h = exact_tri(C.tri64 + 9 * (size_t)ti, o, d, false);
                 if (h.hit && h.t < best.t) { best.gprim = S.n_spheres + ti; best.t = h.t; }
             }
         }

@@ -150,7 +150,48 @@ RT_DEV void best_insert(Best &b, uint32_t key) {
     b.k0 = umin_(b.k0, key);
 }
 
-RT_DEV void tri_candidate(const TriRow &T, const Ray &r, Best &b, uint32_t keep_mask) {
+// Second-pass sink.  When the first pass cannot name the hit on its own (a runner-up whose lower
+// bound is not behind the winner's upper bound, or a winner the double-precision code rejected),
+// the tables are walked once more and every candidate whose key is at or below `limit` is
+// evaluated by the exact code on the spot; the best of those under upstream's ordering (depth,
+// then object order, then face order: scene.py:23-27, mesh.py:101-110) is the hit.  A primitive
+// whose key is above `limit` has a true depth beyond a proven hit and cannot win or tie.
+struct Resolve {
+    const DevScene *S;
+    D3 o, d;
+    int32_t origin, skip;      // skip: the first-pass winner, already evaluated
+    uint32_t limit, keep_mask;
+    ExactHit e; int32_t gprim; uint64_t order;   // best so far; gprim < 0: none
+};
+
+RT_DEV uint64_t scene_order(const DevScene &S, int32_t gprim) {
+    const int32_t obj = gprim < S.n_spheres ? S.sph_obj[gprim] : S.tri_aux[gprim - S.n_spheres].obj;
+    return ((uint64_t)(uint32_t)obj << 32) | (uint32_t)gprim;
+}
+
+RT_DEV void resolve_insert(Resolve &R, uint32_t key) {
+    if (key <= R.limit) {
+        const DevScene &S = *R.S;
+        const int32_t g = (int32_t)(key & S.key_mask);
+        if (g != R.skip) {
+            const ExactHit x = exact_single(S, g, R.o, R.d, R.origin);
+            if (x.hit) {
+                const uint64_t ord = scene_order(S, g);
+                if (R.gprim < 0 || x.t < R.e.t || (x.t == R.e.t && ord < R.order)) {
+                    R.e = x; R.gprim = g; R.order = ord;
+                    const float up = (float)x.t * (1.0f + 2.0f * kU);   // >= x.t
+                    const uint32_t lim = (f2u(up) & R.keep_mask) | S.key_mask;
+                    R.limit = umin_(R.limit, lim);
+                }
+            }
+        }
+    }
+}
+
+struct BestSink { Best b; RT_DEV void operator()(uint32_t key) { best_insert(b, key); } };
+struct ResolveSink { Resolve R; RT_DEV void operator()(uint32_t key) { resolve_insert(R, key); } };
+
+RT_DEV uint32_t tri_key(const TriRow &T, const Ray &r, uint32_t keep_mask) {
     TriEval e = tri_eval(T, r);
     float mp = fma_(e.g, T.cb, e.m);
     float thi = fma_(e.g, T.ct, e.t);
@@ -161,22 +202,22 @@ RT_DEV void tri_candidate(const TriRow &T, const Ray &r, Best &b, uint32_t keep_
     uint32_t key = (f2u(tl) & keep_mask) | (uint32_t)T.gprim;
     // det_lo = +inf marks the padding rows at the end of the table: never candidates (NaN included)
     const bool kill = (T.gprim == r.origin) || !(abs_(e.nd) >= T.det_lo);
-    key = kill ? 0xFFFFFFFFu : key;
-    best_insert(b, key);
+    return kill ? 0xFFFFFFFFu : key;
 }
 
 // Brute-force loop over the live triangles, two rows per trip.  The table is padded with dead rows
 // to an even count plus two, so the loop needs no tail and may read one trip ahead: each row's
 // scalar load is issued a full test (~37 vector instructions) before the row is used.
-RT_DEV void search_tris(const DevScene &S, const Ray &r, Best &b, uint32_t keep_mask) {
+template <class Sink>
+RT_DEV void search_tris(const DevScene &S, const Ray &r, Sink &sink, uint32_t keep_mask) {
     const int n = S.n_tri_rows_padded;   // even; rows [n, n+2) exist and are dead
     if (n <= 0) return;
     const TriRow *rows = S.tri_rows;
     TriRow a0 = load_tri_row_uniform(rows, 0), a1 = load_tri_row_uniform(rows, 1);
     for (int i = 0; i < n; i += 2) {
-        tri_candidate(a0, r, b, keep_mask);
+        sink(tri_key(a0, r, keep_mask));
         a0 = load_tri_row_uniform(rows, i + 2);
-        tri_candidate(a1, r, b, keep_mask);
+        sink(tri_key(a1, r, keep_mask));
         a1 = load_tri_row_uniform(rows, i + 3);
     }
 }
@@ -232,7 +273,8 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
     return o;
 }
 
-RT_DEV void search_spheres(const DevScene &S, const Ray &r, Best &bst, uint32_t keep_mask) {
+template <class Sink>
+RT_DEV void search_spheres(const DevScene &S, const Ray &r, Sink &sink, uint32_t keep_mask) {
     const int n = S.n_sph_rows;
     const SphRow *rows = S.sph_rows;
 #pragma unroll 2
@@ -242,19 +284,38 @@ RT_DEV void search_spheres(const DevScene &S, const Ray &r, Best &bst, uint32_t 
         float b = fma_(roz, r.dz, fma_(roy, r.dy, rox * r.dx));
         float cq = fma_(roz, roz, fma_(roy, roy, fma_(rox, rox, -P.r2)));
         float disc = fma_(b, b, -(r.a * cq));
-        if (disc >= -r.band0) {  // rare per lane: the precise bounds are worked out in here
-            SphBounds o = sphere_bounds(P, r);
+        if (disc >= -r.band0) {
+            // Candidate.  Only a cheap, loose lower bound on the depth is formed here (band0 bounds the
+            // discriminant error for every sphere of the scene); the winner's precise bounds are
+            // worked out once, after the loops.
+            const float sh = sqrt_(disc + r.band0) * (1.0f + 4.0f * kU);
+            const float eb = kU * r.dlen * (6.0f * (abs_(rox) + abs_(roy) + abs_(roz)) + 2.0f * P.cn + r.o2);
+            const float nb = -b;
+            const float t1lo = (nb - sh - eb) * r.inv_a, t2hi = (nb + sh + eb) * r.inv_a, t2lo = (nb - eb) * r.inv_a;
             bool valid; float tl;
             if (P.gprim == r.origin) {           // only the far root, only when heading inwards
-                valid = o.maybe && (o.b < o.eb);
-                tl = max_(o.t2lo, 0.0f);
+                valid = b < eb;
+                tl = t2lo;
             } else {
-                valid = o.maybe && (o.t2hi > 0.0f);
-                tl = (o.t1hi > 0.0f) ? max_(o.t1lo, 0.0f) : max_(o.t2lo, 0.0f);
+                valid = t2hi > 0.0f;
+                tl = t1lo;
             }
+            tl = max_(tl, 0.0f) * (1.0f - 8.0f * kU);
             uint32_t key = valid ? ((f2u(tl) & keep_mask) | (uint32_t)P.gprim) : 0xFFFFFFFFu;
-            best_insert(bst, key);
+            sink(key);
         }
+    }
+}
+
+// The few huge spheres: double precision throughout.
+template <class Sink>
+RT_DEV void search_big_spheres(const DevScene &S, const Ray &r, D3 o64, D3 d64, Sink &sink, uint32_t keep_mask) {
+    for (int i = 0; i < S.n_big_sph; ++i) {
+        int si = S.big_sph[i];
+        ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
+        float tl = (float)eb.t * (1.0f - 4.0f * kU);
+        uint32_t key = eb.hit ? ((f2u(tl) & keep_mask) | (uint32_t)si) : 0xFFFFFFFFu;
+        sink(key);
     }
 }
 
@@ -305,6 +366,24 @@ struct RayResidue { const float *table; uint32_t pixel; float ox, oy, oz; };
 
 RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r.ox = r.oy = r.oz = 0.0f; return r; }
 
+// The rare passes live out of line: inlined, their register needs would be charged to the hot loops.
+template <bool HAS_TRI, bool HAS_SPH>
+RT_DEV void resolve_pass(const DevScene &S, const Ray &r, D3 o64, D3 d64, ResolveSink &rs) {
+    if (HAS_SPH) {
+        search_spheres(S, r, rs, rs.R.keep_mask);
+        search_big_spheres(S, r, o64, d64, rs, rs.R.keep_mask);
+    }
+    if (HAS_TRI) search_tris(S, r, rs, rs.R.keep_mask);
+}
+
+RT_DEV void exact_scan_pass(const DevScene &S, D3 o64, D3 d64, int32_t origin, ExactHit &e, int32_t &gprim) {
+    ScanHit sh = exact_scan(S, o64, d64, origin);
+    gprim = sh.gprim;
+    e.hit = false;
+    if (gprim >= 0) e = exact_single(S, gprim, o64, d64, origin);
+    if (!e.hit) gprim = -1;
+}
+
 // `e64`, when given, receives the double-precision record whenever the exact code produced the hit
 // (e64->hit says whether it did).
 template <bool HAS_TRI, bool HAS_SPH, bool STRICT>
@@ -323,18 +402,14 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
     int32_t gprim = -1; int root = 0; float t = kInf;
     if (!scan) {
         const uint32_t keep_mask = ~S.key_mask;
-        Best b; b.k0 = 0xFFFFFFFFu; b.k1 = 0xFFFFFFFFu;
+        BestSink first; first.b.k0 = 0xFFFFFFFFu; first.b.k1 = 0xFFFFFFFFu;
         if (HAS_SPH) {
-            search_spheres(S, r, b, keep_mask);
-            for (int i = 0; i < S.n_big_sph; ++i) {   // the few huge spheres: double precision throughout
-                int si = S.big_sph[i];
-                ExactHit eb = exact_sphere(S.sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
-                float tl = (float)eb.t * (1.0f - 4.0f * kU);
-                uint32_t key = eb.hit ? ((f2u(tl) & keep_mask) | (uint32_t)si) : 0xFFFFFFFFu;
-                best_insert(b, key);
-            }
+            search_spheres(S, r, first, keep_mask);
+            search_big_spheres(S, r, o64, d64, first, keep_mask);
         }
-        if (HAS_TRI) search_tris(S, r, b, keep_mask);
+        if (HAS_TRI) search_tris(S, r, first, keep_mask);
+        const Best b = first.b;
+        bool second = false; uint32_t limit = 0; int32_t skip = -1;
         if (b.k0 < kKeyNone) {
             gprim = (int32_t)(b.k0 & S.key_mask);
             const float second_lo = u2f(b.k1 & keep_mask);
@@ -347,30 +422,45 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
                 Verdict v = judge_tri(S, gprim - S.n_spheres, r, STRICT ? kRelAcceptStrict : kRelAcceptRender);
                 status = v.status; t = v.t; thi = v.thi;
             }
+            skip = gprim;
             if (status == 1 && gprim >= S.n_spheres) {
                 // a triangle that is certainly the hit but whose float32 depth is too coarse (grazing
                 // incidence): only the depth is redone in double precision
                 cnt.refine++;
-                t = (float)exact_tri_depth(S.tri64 + 9 * (size_t)(gprim - S.n_spheres), o64, d64);
+                t = (float)exact_tri_depth(S.cold->tri64 + 9 * (size_t)(gprim - S.n_spheres), o64, d64);
                 thi = t * (1.0f + 2.0f * kU);
                 h.how = 1;
             } else if (status != 0) {   // undecided, or an imprecise sphere: double precision for this primitive
                 cnt.refine++;
                 e = exact_single(S, gprim, o64, d64, r.origin);
-                if (!e.hit) scan = true;            // the winner was not a hit after all
-                else { t = (float)e.t; thi = t * (1.0f + 2.0f * kU); root = e.prim; }
+                if (e.hit) { t = (float)e.t; thi = t * (1.0f + 2.0f * kU); root = e.prim; }
             }
-            if (has_second && !(second_lo > thi)) scan = true;   // someone else may be in front, or tie
+            if (status == 2 && !e.hit) {
+                // the winner was not a hit after all: every other candidate is open
+                second = has_second; limit = kKeyNone - 1u; gprim = -1;
+            } else if (has_second && !(second_lo > thi)) {
+                // someone else may be in front, or tie: the contenders are settled in double precision
+                second = true; limit = (f2u(thi) & keep_mask) | S.key_mask;
+                if (!e.hit) e = exact_single(S, gprim, o64, d64, r.origin);
+                if (!e.hit) { limit = kKeyNone - 1u; gprim = -1; }   // cannot happen for a certain winner; stay safe
+            }
+        }
+        if (second) {
+            cnt.exact++;
+            h.how = 2;
+            ResolveSink rs;
+            rs.R.S = &S; rs.R.o = o64; rs.R.d = d64; rs.R.origin = r.origin; rs.R.skip = skip;
+            rs.R.limit = limit; rs.R.keep_mask = keep_mask;
+            rs.R.e = e; rs.R.gprim = gprim; rs.R.order = gprim >= 0 ? scene_order(S, gprim) : 0;
+            resolve_pass<HAS_TRI, HAS_SPH>(S, r, o64, d64, rs);
+            e = rs.R.e; gprim = rs.R.gprim;
+            if (gprim < 0) e.hit = false;
         }
     }
     if (scan) {   // upstream's Scene.intersect, literally, in double precision
         cnt.exact++;
         h.how = 2;
-        ScanHit sh = exact_scan(S, o64, d64, r.origin);
-        gprim = sh.gprim;
-        e.hit = false;
-        if (gprim >= 0) e = exact_single(S, gprim, o64, d64, r.origin);
-        if (!e.hit) gprim = -1;
+        exact_scan_pass(S, o64, d64, r.origin, e, gprim);
     }
     if (e64) *e64 = e;
     if (gprim < 0) return h;

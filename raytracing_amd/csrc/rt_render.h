@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene S, int W, int H, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W * H) return;
     const int x = i / H, y = i - x * H;
-    const double *c = S.cam64;
+    const double *c = S.cold->cam64;
     const double aspect = (double)H / (double)W;
     const double u = (x + 0.5) / W * 2 - 1;
     const double v = (y + 0.5) / H * 2 * aspect - aspect;
@@ -148,7 +148,7 @@ RT_DEV void camera_ray(const DevScene &S, const float *ray_dir, const float *ray
     ox = S.cam_pos[0]; oy = S.cam_pos[1]; oz = S.cam_pos[2];
     rr.table = ray_res; rr.pixel = pixel; rr.ox = S.cam_res[0]; rr.oy = S.cam_res[1]; rr.oz = S.cam_res[2];
     if (S.dof_on) {
-        const double *c = S.cam64;
+        const double *c = S.cold->cam64;
         const f4 e = *(const f4 *)(ray_res + 4 * (size_t)pixel);
         const double ddx = (double)q.x + (double)e.x, ddy = (double)q.y + (double)e.y, ddz = (double)q.z + (double)e.z;
         const Draws dr = segment_draws(key0, key1, 0);
@@ -252,6 +252,11 @@ RT_DEV bool path_step(const DevScene &S, Path &p, int max_bounces, HitCounters &
     return alive;
 }
 
+RT_DEV uint32_t fast_div(uint32_t n, const FastDiv &f) {
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 RT_DEV uint32_t rank_in(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -294,9 +299,10 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
             uint32_t r = rank_in(idle);
             if (!have_job && r < avail) {
                 uint32_t job = win_next + r;
-                uint32_t chunk = job / rect_px, pl = job - chunk * rect_px;
-                px = A.x0 + (int)(pl / (uint32_t)A.rect_h);
-                py = A.y0 + (int)(pl % (uint32_t)A.rect_h);
+                const uint32_t chunk = fast_div(job, A.div_rect_px), pl = job - chunk * rect_px;
+                const uint32_t col = fast_div(pl, A.div_rect_h);
+                px = A.x0 + (int)col;
+                py = A.y0 + (int)(pl - col * (uint32_t)A.rect_h);
                 pixel = (uint32_t)(px * A.height + py);
                 slot = job;
                 s_cur = A.sample_begin + (int)chunk * A.chunk_samples;

@@ -54,6 +54,20 @@ struct BvhNode {     // mirrors rt_bvh_node
     float hi[3]; int32_t tri_begin_count;
 };
 
+// Scene data only the rare double-precision code, the depth-of-field camera and the ray-generation
+// kernel read.  It lives in device memory behind DevScene::cold, so that the render kernel does not
+// pin ~50 scalar registers on it for the whole launch (which the compiler paid for by spilling
+// scalars into vector-register lanes inside the hot loop).
+struct ColdScene {
+    const double *tri64;      // [n_tris][9] vertices as the host holds them
+    const double *sph64;      // [n_spheres][4]
+    const double *aabb64;     // [n_meshes][6]
+    const int32_t *mesh_tri_begin;  // [n_meshes+1]
+    const int32_t *obj_kind, *obj_index;
+    int32_t n_objects, n_tris, n_meshes, pad;
+    double cam64[15];         // pos, right, up, forward (3 each), d, dof_strength, dof_dist
+};
+
 struct DevScene {
     // float32 filter tables
     const TriRow *tri_rows;   int32_t n_tri_rows;     // live triangles only, padded with dead rows:
@@ -65,28 +79,20 @@ struct DevScene {
     const SphRow *sph_by_id;                          // [n_spheres]
     const int32_t *sph_obj;                           // [n_spheres]
     const MatRow *materials;                          // [n_objects]
-    // float64 tables (exact code)
-    const double *tri64;      // [n_tris][9]
-    const double *sph64;      // [n_spheres][4]
-    const double *aabb64;     // [n_meshes][6]
-    const int32_t *mesh_tri_begin;  // [n_meshes+1]
-    const int32_t *obj_kind, *obj_index;
-    int32_t n_objects, n_spheres, n_tris, n_meshes;
-    // BVH (optional)
-    const BvhNode *bvh; int32_t n_bvh; const int32_t *bvh_tri;
-    // scalars
+    const ColdScene *cold;                            // device memory
+    int32_t n_spheres;
     float scene_radius;       // bound on the distance from the world origin of every vertex, small-sphere point and the camera
     uint32_t key_mask;        // low bits of a hit key that hold the primitive id
-    int32_t any_det_cut;      // some live triangle has det_lo > 0
-    // camera (camera.py:17-37)
-    float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
-    float cam_d, dof_strength, dof_dist;
+    // camera: float32 position and its double-precision residue (pinhole rays come from k_raygen's table)
+    float cam_pos[3], cam_res[3];
     int32_t dof_on;
-    double cam64[15];         // pos, right, up, forward (3 each), d, dof_strength, dof_dist as the host holds them
-    float cam_res[3];         // cam64 position minus its float32 rounding
     // environment: RGBA8 texels, row-major
     const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale;
 };
+
+// Division of a 32-bit unsigned by a launch-invariant divisor (Granlund & Montgomery): the host fills
+// the constants, the device spends a multiply-high and two shifts instead of a ~30-instruction divide.
+struct FastDiv { uint32_t d, m, sh1, sh2; };
 
 struct RenderArgs {
     int32_t width, height, x0, y0, rect_w, rect_h;
@@ -97,6 +103,7 @@ struct RenderArgs {
     int32_t max_bounces;
     uint32_t seed_lo, seed_hi;
     uint32_t total_jobs;
+    FastDiv div_rect_px, div_rect_h;   // job -> (chunk, pixel in rectangle) -> (x, y)
     uint32_t *job_counter;    // device word, zero at launch
     float *accum;             // (W,H,3) running sum
     float *partial;           // [n_chunks][rect_w*rect_h][3] when n_chunks > 1, else unused
