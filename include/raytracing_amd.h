@@ -109,7 +109,7 @@ typedef struct rt_stats {
     uint64_t rays;                 /* closest-hit queries = Scene.intersect calls (scene.py:23) */
     uint64_t paths;                /* top-level raytrace calls (renderer.py:105) */
     uint64_t sphere_tests, tri_tests, aabb_tests, bvh_node_tests; /* float32 filter tests executed */
-    uint64_t exact_rays;           /* rays answered by the double-precision scan of the whole scene */
+    uint64_t exact_rays;           /* rays whose contenders were settled in double precision (second pass or whole-scene scan) */
     uint64_t refined_hits;         /* hits whose winning primitive was re-evaluated in double precision */
     uint64_t sky_lookups, shaded_hits;
     double kernel_ms;              /* device time of the dominant kernel, summed over launches */
@@ -137,7 +137,8 @@ int rt_set_scene(rt_ctx *ctx, const rt_scene_desc *scene);
  * bounce rays do: value = global primitive id as returned in `gprim` (sphere index, or n_spheres +
  * triangle index), -1 = none; NULL gives upstream's semantics unchanged.  `how` (may be NULL)
  * reports which code produced each answer: 0 = float32 filter alone, 1 = winning primitive
- * re-evaluated in double precision, 2 = whole scene re-evaluated in double precision. */
+ * re-evaluated in double precision, 2 = every contender (or the whole scene) re-evaluated in double
+ * precision. */
 int rt_intersect_batch(rt_ctx *ctx, int64_t n, const double *org, const double *dir,
                        const int32_t *origin_prim, int32_t *obj, int32_t *prim, int32_t *gprim,
                        int32_t *how, double *t, double *normal, double *pos);
