@@ -78,9 +78,11 @@ typedef struct rt_scene_desc {
     const uint8_t *sky_rgb;        /* [sky_h][sky_w][3] row-major, as decoded from the image file */
     double sky_scale;              /* radiance = texel/255 * sky_scale */
 
-    /* Optional host-built flat BVH over ALL triangles (no upstream counterpart: it replaces the
-     * linear loops of Mesh.intersect, src/mesh/mesh.py:94-107).  n_bvh_nodes == 0 selects the
-     * brute-force kernels.  Layout: see rt_bvh_node. */
+    /* Optional flat bounding-volume hierarchy over ALL triangles (no upstream counterpart: it
+     * replaces the linear loops of Mesh.intersect, src/mesh/mesh.py:94-107, and returns the same
+     * hits).  n_bvh_nodes > 0: the caller's hierarchy (checked: links, coverage, containment);
+     * n_bvh_nodes == 0: linear table walk up to 4096 primitives, a hierarchy built by the library
+     * beyond that; n_bvh_nodes < 0: the library builds one whatever the size.  Layout: rt_bvh_node. */
     int32_t n_bvh_nodes;
     const void *bvh_nodes;         /* [n_bvh_nodes] rt_bvh_node */
     const int32_t *bvh_tri_index;  /* [n_tris] triangle ids in leaf order */
@@ -92,7 +94,7 @@ typedef struct rt_bvh_node {
     float lo[3];
     int32_t skip;                  /* index of the node to continue with on a miss; -1 = done */
     float hi[3];
-    int32_t tri_begin_count;       /* leaf: (first << 4) | count (count 1..15); inner: -1 */
+    int32_t tri_begin_count;       /* leaf: (first << 4) | count (count 1..15), first indexes bvh_tri_index; inner: -1 */
 } rt_bvh_node;
 
 typedef struct rt_render_params {
@@ -125,6 +127,15 @@ int rt_abi_version(void);
 int rt_create(int device_id, rt_ctx **out);
 int rt_destroy(rt_ctx *ctx);
 const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: last error of a failed rt_create */
+
+/* Host-side hierarchy builder (binned surface-area heuristic; CPU only, needs no context or GPU).
+ * No upstream counterpart (upstream has no acceleration structure).  tri_verts = [n_tris][9] as in
+ * rt_scene_desc; leaf_size = triangles per leaf to aim for (<= 0: 4).  Writes the leaf-order
+ * triangle ids to tri_index_out[n_tris], the node count to *n_nodes_out and, when nodes_out is
+ * non-NULL and nodes_capacity suffices (2 * n_tris always does), the nodes.  Call with
+ * nodes_out = NULL to learn the count first. */
+int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_bvh_node *nodes_out,
+                 int32_t nodes_capacity, int32_t *tri_index_out, int32_t *n_nodes_out);
 
 /* Scene upload: what Renderer.init_render binds (renderer.py:81-88, `self.scene = ...SCENE`). */
 int rt_set_scene(rt_ctx *ctx, const rt_scene_desc *scene);

@@ -251,6 +251,8 @@ static int scene_intersect(const rt_scene_desc *s, v3 o, v3 d, hit_rec *best, in
 void orc_intersect_batch(const rt_scene_desc *s, int64_t n, const double *org, const double *dir,
                          const int32_t *origin_prim, int32_t *obj, int32_t *prim, int32_t *gprim,
                          double *t, double *normal, double *pos, int32_t *n_hits) {
+    /* rays are independent; threads only make big brute-force batches bearable */
+#pragma omp parallel for schedule(dynamic, 16) if (n >= 256)
     for (int64_t i = 0; i < n; ++i) {
         hit_rec h;
         int k = scene_intersect(s, V(org[3 * i], org[3 * i + 1], org[3 * i + 2]),

@@ -24,7 +24,7 @@ RT_ERR_STOPPED = 5
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
            "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms",
-           "rt_debug_trace_paths"]
+           "rt_debug_trace_paths", "rt_build_bvh"]
 
 
 class RtRenderParams(C.Structure):
@@ -85,6 +85,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_debug_uniforms.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int32, fp]
     lib.rt_debug_trace_paths.argtypes = [vp, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                          fp, ip, ip, ip, ip, fp, fp, fp]
+    lib.rt_build_bvh.argtypes = [C.c_int32, dp, C.c_int32, vp, C.c_int32, ip, ip]
     if path is None:
         _lib = lib
     return lib

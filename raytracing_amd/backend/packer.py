@@ -97,6 +97,7 @@ class PackedScene:
     sky_scale: float = 1.0
     bvh_nodes: Optional[np.ndarray] = None      # structured (n,) rt_bvh_node
     bvh_tri_index: Optional[np.ndarray] = None  # (n_tri,) int32
+    library_bvh: bool = False                   # no host hierarchy: ask the library to build one whatever the size
     object_names: list = field(default_factory=list)
 
     @property
@@ -151,10 +152,29 @@ class PackedScene:
             d.bvh_nodes = self.bvh_nodes.ctypes.data_as(C.c_void_p)
             d.bvh_tri_index = _ptr(self.bvh_tri_index, C.c_int32)
         else:
-            d.n_bvh_nodes = 0
+            d.n_bvh_nodes = -1 if self.library_bvh else 0
             d.bvh_nodes = None
             d.bvh_tri_index = C.cast(None, C.POINTER(C.c_int32))
         return d
+
+    def with_subdivided_mesh(self, mesh: int, levels: int) -> "PackedScene":
+        """Copy of the scene in which every triangle of mesh ``mesh`` is split ``levels`` times into
+        four by its edge midpoints (same surface, 4**levels times the faces; face order: for each
+        parent in order its corner triangles at a, b, c, then the middle one).  Used to synthesise
+        large meshes from small model files; any hierarchy is dropped."""
+        import dataclasses
+
+        b0, b1 = int(self.mesh_tri_begin[mesh]), int(self.mesh_tri_begin[mesh + 1])
+        tv = self.tri_verts[b0:b1].reshape(-1, 3, 3)
+        for _ in range(int(levels)):
+            a, b, c = tv[:, 0], tv[:, 1], tv[:, 2]
+            ab, bc, ca = (a + b) * 0.5, (b + c) * 0.5, (c + a) * 0.5
+            tv = np.stack([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1), np.stack([ca, bc, c], 1),
+                           np.stack([ab, bc, ca], 1)], 1).reshape(-1, 3, 3)
+        new = np.ascontiguousarray(np.concatenate([self.tri_verts[:b0], tv.reshape(-1, 9), self.tri_verts[b1:]], 0))
+        begin = self.mesh_tri_begin.copy()
+        begin[mesh + 1:] += np.int32(tv.shape[0] - (b1 - b0))
+        return dataclasses.replace(self, tri_verts=new, mesh_tri_begin=begin, bvh_nodes=None, bvh_tri_index=None)
 
     # -- persistence (fixtures / hand-off to a machine without the scene sources) ---------------
     def save(self, path: str, with_sky: bool = True) -> None:
@@ -258,11 +278,14 @@ def _find_environment(scene: Any) -> tuple[Optional[np.ndarray], float]:
 
 
 # ---------------------------------------------------------------------------------------------
-def pack_scene(scene: Any, build_bvh: bool | None = None) -> PackedScene:
+def pack_scene(scene: Any, build_bvh: bool | None = None, sky_rgb: Optional[np.ndarray] = None,
+               sky_scale: Optional[float] = None) -> PackedScene:
     """Flatten ``scene`` (this package's or upstream's) into a :class:`PackedScene`.
 
-    ``build_bvh``: None = build the flat BVH when the scene has more triangles than the brute-force
-    kernels handle well; True / False force it.
+    ``build_bvh``: None = leave the choice to the library (linear table walk up to 4096 primitives,
+    a hierarchy it builds itself beyond); True = build the hierarchy here with the native builder and
+    hand it over; False = none from here.  ``sky_rgb`` (H, W, 3 uint8) / ``sky_scale`` override the
+    environment found on the scene (needed when the scene's sky closure is opaque).
     """
     kinds, index, mats, names = [], [], [], []
     spheres, sphere_obj = [], []
@@ -297,7 +320,13 @@ def pack_scene(scene: Any, build_bvh: bool | None = None) -> PackedScene:
         else:
             raise TypeError(f"scene.objects[{oi}] is neither a sphere (radius) nor a mesh (triangles)")
     cam = scene.camera
-    sky_rgb, sky_scale = _find_environment(scene)
+    found_rgb, found_scale = _find_environment(scene)
+    if sky_rgb is None:
+        sky_rgb = found_rgb
+    else:
+        sky_rgb = np.ascontiguousarray(sky_rgb, dtype=np.uint8)
+    if sky_scale is None:
+        sky_scale = found_scale
     packed = PackedScene(
         obj_kind=np.asarray(kinds, dtype=np.int32),
         obj_index=np.asarray(index, dtype=np.int32),
@@ -313,13 +342,8 @@ def pack_scene(scene: Any, build_bvh: bool | None = None) -> PackedScene:
         cam_d=float(cam.d), cam_dof_strength=float(cam.dof_strength), cam_dof_dist=float(cam.dof_dist),
         sky_rgb=sky_rgb, sky_scale=sky_scale, object_names=names,
     )
-    if build_bvh is None:
-        build_bvh = packed.n_tris > BVH_AUTO_THRESHOLD
     if build_bvh and packed.n_tris:
         from .bvh import build_flat_bvh
 
         packed.bvh_nodes, packed.bvh_tri_index = build_flat_bvh(packed.tri_verts)
     return packed
-
-
-BVH_AUTO_THRESHOLD = 256

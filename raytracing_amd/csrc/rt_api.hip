@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/raytracing_amd.h"
+#include "rt_bvh_build.h"
 #include "rt_exact.h"
 #include "rt_filter.h"
 #include "rt_render.h"
@@ -58,7 +59,7 @@ struct rt_ctx {
     std::atomic<int> stop{0};
     bool has_scene = false;
     DevScene S{};
-    bool has_tri = false, has_sph = false;
+    int tri_mode = 0; bool has_sph = false;
     DevBuf tri_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
@@ -145,6 +146,18 @@ int rt_destroy(rt_ctx *ctx) {
     return RT_OK;
 }
 
+int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_bvh_node *nodes_out, int32_t nodes_capacity,
+                 int32_t *tri_index_out, int32_t *n_nodes_out) {
+    if (n_tris <= 0 || n_tris >= (1 << 27) || !tri_verts || !tri_index_out || !n_nodes_out || nodes_capacity < 0) return RT_ERR_INVALID_ARG;
+    bvh::Builder b;
+    b.run(n_tris, tri_verts, leaf_size > 0 ? leaf_size : 4);
+    *n_nodes_out = (int32_t)b.nodes.size();
+    std::memcpy(tri_index_out, b.order.data(), sizeof(int32_t) * (size_t)n_tris);
+    if ((int64_t)b.nodes.size() > nodes_capacity || !nodes_out) return nodes_out ? RT_ERR_INVALID_ARG : RT_OK;
+    std::memcpy(nodes_out, b.nodes.data(), sizeof(rt_bvh_node) * b.nodes.size());
+    return RT_OK;
+}
+
 int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     if (!c || !d) return fail(c, RT_ERR_INVALID_ARG, "rt_set_scene: NULL argument");
     if (d->struct_size != sizeof(rt_scene_desc))
@@ -165,9 +178,28 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         return fail(c, RT_ERR_INVALID_ARG, "mesh_tri_begin does not span [0, n_tris]");
     for (int m = 0; m < d->n_meshes; ++m)
         if (d->mesh_tri_begin[m + 1] < d->mesh_tri_begin[m]) return fail(c, RT_ERR_INVALID_ARG, "mesh_tri_begin not monotone");
-    if (d->n_bvh_nodes > 0) return fail(c, RT_ERR_UNSUPPORTED, "BVH traversal kernels are not built yet; pass n_bvh_nodes = 0");
     const long long n_gprim = (long long)d->n_spheres + d->n_tris;
-    if (n_gprim > 4096) return fail(c, RT_ERR_UNSUPPORTED, "%lld primitives: the brute-force kernels take at most 4096", n_gprim);
+    if (d->n_tris >= (1 << 27)) return fail(c, RT_ERR_UNSUPPORTED, "%d triangles: at most 2^27 - 1", d->n_tris);
+    // Triangle search: the linear table walk up to 4096 primitives, the hierarchy beyond that (built
+    // here when the caller brings none) or whenever the caller asks for it (n_bvh_nodes != 0).
+    const bool use_bvh = d->n_tris > 0 && (d->n_bvh_nodes != 0 || n_gprim > 4096);
+    if (!use_bvh && n_gprim > 4096)
+        return fail(c, RT_ERR_UNSUPPORTED, "%lld primitives without triangles: the linear sphere walk takes at most 4096", n_gprim);
+    std::vector<rt_bvh_node> bvh_nodes; std::vector<int32_t> bvh_order;
+    if (use_bvh) {
+        if (d->n_bvh_nodes > 0) {
+            if (!d->bvh_nodes || !d->bvh_tri_index) return fail(c, RT_ERR_INVALID_ARG, "n_bvh_nodes > 0 with a NULL table");
+            const rt_bvh_node *nn = static_cast<const rt_bvh_node *>(d->bvh_nodes);
+            const std::string why = bvh::validate(d->n_bvh_nodes, nn, d->n_tris, d->bvh_tri_index, d->tri_verts);
+            if (!why.empty()) return fail(c, RT_ERR_INVALID_ARG, "bad hierarchy: %s", why.c_str());
+            bvh_nodes.assign(nn, nn + d->n_bvh_nodes);
+            bvh_order.assign(d->bvh_tri_index, d->bvh_tri_index + d->n_tris);
+        } else {
+            bvh::Builder b;
+            b.run(d->n_tris, d->tri_verts, 4);
+            bvh_nodes.swap(b.nodes); bvh_order.swap(b.order);
+        }
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
 
@@ -282,7 +314,12 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     std::vector<int32_t> okind(d->obj_kind, d->obj_kind + d->n_objects), oindex(d->obj_index, d->obj_index + d->n_objects);
     std::vector<int32_t> sobj(d->sphere_obj, d->sphere_obj + d->n_spheres);
     // pad the live rows with dead ones (det_lo = +inf) to an even count, plus two to read ahead
-    const int n_live = (int)rows_live.size();
+    int n_live = (int)rows_live.size();
+    if (use_bvh) {   // the walk reads rows in leaf order (dead triangles included: they kill themselves)
+        rows_live.resize(d->n_tris);
+        for (int k = 0; k < d->n_tris; ++k) rows_live[k] = rows_all[bvh_order[k]];
+        n_live = d->n_tris;
+    }
     if (n_live) {
         TriRow dead{}; dead.kn = 1; dead.k1 = dead.k2 = -1; dead.det_lo = INFINITY; dead.gprim = -2;
         while (rows_live.size() % 2) rows_live.push_back(dead);
@@ -294,6 +331,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
     HIP_TRY(c, c->mesh_tri_begin.upload(mtb)); HIP_TRY(c, c->obj_kind.upload(okind)); HIP_TRY(c, c->obj_index.upload(oindex));
     if (has_sky) HIP_TRY(c, c->sky.upload(sky));
+    if (use_bvh) HIP_TRY(c, c->bvh.upload(bvh_nodes));
 
     DevScene &S = c->S;
     S = DevScene{};
@@ -303,6 +341,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();
     S.sph_by_id = c->sph_by_id.as<SphRow>(); S.sph_obj = c->sph_obj.as<int32_t>();
     S.materials = c->materials.as<MatRow>();
+    S.bvh_nodes = use_bvh ? c->bvh.as<BvhNode>() : nullptr; S.n_bvh_nodes = use_bvh ? (int32_t)bvh_nodes.size() : 0;
     ColdScene cold{};
     cold.tri64 = c->tri64.as<double>(); cold.sph64 = c->sph64.as<double>(); cold.aabb64 = c->aabb64.as<double>();
     cold.mesh_tri_begin = c->mesh_tri_begin.as<int32_t>(); cold.obj_kind = c->obj_kind.as<int32_t>(); cold.obj_index = c->obj_index.as<int32_t>();
@@ -318,12 +357,12 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.n_spheres = d->n_spheres;
     S.scene_radius = up(scene_radius * 1.000001);
     int bits = 5;
-    while ((1ll << bits) < n_gprim) ++bits;
+    while ((1ll << bits) < n_gprim && bits < 23) ++bits;   // only the linear walk's 32-bit keys use it
     S.key_mask = (1u << bits) - 1u;
     S.dof_on = !(d->cam_dof_dist == 0 || d->cam_dof_strength == 0);   // camera.py:41
     S.sky = has_sky ? c->sky.as<uint32_t>() : nullptr; S.sky_w = has_sky ? d->sky_w : 0; S.sky_h = has_sky ? d->sky_h : 0;
     S.sky_scale = (float)d->sky_scale;
-    c->has_tri = n_live > 0; c->has_sph = d->n_spheres > 0;
+    c->tri_mode = use_bvh ? kTriBvh : (n_live > 0 ? kTriBrute : kTriNone); c->has_sph = d->n_spheres > 0;
     c->ray_w = c->ray_h = 0;   // camera changed: the ray table is stale
     c->has_scene = true;
     return RT_OK;
@@ -358,7 +397,7 @@ struct IsectArgs {
     unsigned long long *stats;
 };
 
-template <bool HAS_TRI, bool HAS_SPH>
+template <int TRI, bool HAS_SPH>
 __global__ __launch_bounds__(256) void k_intersect(const DevScene S, const IsectArgs A) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
@@ -372,10 +411,10 @@ __global__ __launch_bounds__(256) void k_intersect(const DevScene S, const Isect
                          (double)fdy == dy && (double)fdz == dz;
     ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.how = 2;
-    HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
+    HitCounters cnt; cnt.exact = 0; cnt.refine = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0;
     if (f32_ray) {
         Ray r = make_ray(S, fox, foy, foz, fdx, fdy, fdz, origin, false);
-        h = closest_hit<HAS_TRI, HAS_SPH, true>(S, r, cnt, &e, no_residue());
+        h = closest_hit<TRI, HAS_SPH, true>(S, r, cnt, &e, no_residue());
     } else {
         const D3 o64 = d3(ox, oy, oz), d64 = d3(dx, dy, dz);
         ScanHit sh = exact_scan(S, o64, d64, origin);
@@ -407,10 +446,11 @@ __global__ __launch_bounds__(256) void k_intersect(const DevScene S, const Isect
     if (cnt.refine) atomicAdd(A.stats + kStatRefine, (unsigned long long)cnt.refine);
 }
 
-template <class F> void dispatch_variant(bool tri, bool sph, F &&f) {
-    if (tri && sph) f(std::true_type{}, std::true_type{});
-    else if (tri) f(std::true_type{}, std::false_type{});
-    else f(std::false_type{}, std::true_type{});
+template <class F> void dispatch_variant(int tri, bool sph, F &&f) {
+    using std::integral_constant;
+    if (tri == kTriBvh) { if (sph) f(integral_constant<int, kTriBvh>{}, std::true_type{}); else f(integral_constant<int, kTriBvh>{}, std::false_type{}); }
+    else if (tri == kTriBrute) { if (sph) f(integral_constant<int, kTriBrute>{}, std::true_type{}); else f(integral_constant<int, kTriBrute>{}, std::false_type{}); }
+    else f(integral_constant<int, kTriNone>{}, std::true_type{});
 }
 
 }  // namespace
@@ -441,7 +481,7 @@ int rt_intersect_batch(rt_ctx *c, int64_t n, const double *org, const double *di
     A.t = b_t.as<double>(); A.normal = b_n.as<double>(); A.pos = b_p.as<double>(); A.stats = c->stats.as<unsigned long long>();
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const DevScene S = c->S;
-    dispatch_variant(c->has_tri, c->has_sph, [&](auto T, auto P) {
+    dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
         hipLaunchKernelGGL((k_intersect<decltype(T)::value, decltype(P)::value>), dim3(blocks), dim3(256), 0, 0, S, A);
     });
     HIP_TRY(c, hipGetLastError());
@@ -545,7 +585,7 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b));
     HIP_TRY(c, hipEventRecord(ev.a, stream));
     const DevScene S = c->S;
-    dispatch_variant(c->has_tri, c->has_sph, [&](auto T, auto P) {
+    dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
         hipLaunchKernelGGL((k_render<decltype(T)::value, decltype(P)::value>), dim3(blocks), dim3(256), 0, stream, S, A);
     });
     HIP_TRY(c, hipGetLastError());
@@ -660,7 +700,7 @@ extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *x
     A.seg_prim = b_prim.as<int32_t>(); A.seg_how = b_how.as<int32_t>(); A.seg_t = b_t.as<float>();
     A.seg_org = b_org.as<float>(); A.seg_dir = b_dir.as<float>();
     const DevScene S = c->S;
-    dispatch_variant(c->has_tri, c->has_sph, [&](auto T, auto P) {
+    dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
         hipLaunchKernelGGL((k_trace_paths<decltype(T)::value, decltype(P)::value>),
                            dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, 0, S, A);
     });

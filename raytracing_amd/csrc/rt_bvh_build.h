@@ -1,0 +1,203 @@
+// Host-side builder of the flat bounding-volume hierarchy over triangles (binned surface-area
+// heuristic, top-down), and the checks rt_set_scene runs on a hierarchy before trusting it.
+//
+// No upstream counterpart: upstream tests every face of every mesh for every ray
+// (src/mesh/mesh.py:94-107).  The hierarchy only decides WHICH triangles the kernels test; it must
+// never hide one a ray could hit, so every box contains its triangles (boxes are rounded outward
+// to float32 here and padded again on upload by the kernels' own rounding allowance).
+//
+// Layout ("threaded" depth-first order): the children of an inner node i are node i + 1 and the
+// node that follows the first child's subtree; `skip` is the node that follows node i's whole
+// subtree (-1 after the last one).  Traversal needs no stack: on a box hit go to i + 1 (inner) or
+// test the leaf's triangles and go to skip; on a miss go to skip.  skip > i always, so every walk
+// terminates.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracing_amd.h"
+
+namespace rt {
+namespace bvh {
+
+inline float round_down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -INFINITY) : f; }
+inline float round_up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; }
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; } }
+    void grow(const Box &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    void grow(const float *p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    double half_area() const {
+        double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Builder {
+    static constexpr int kBins = 16;
+    static constexpr int kMaxLeaf = 15;       // rt_bvh_node packs the count in 4 bits
+    int leaf_target;                          // split until a node holds at most this many
+    std::vector<Box> tri_box;                 // per triangle
+    std::vector<float> centroid;              // [n][3]
+    std::vector<int32_t> order;               // triangle ids, permuted in place; final leaf order
+    std::vector<rt_bvh_node> nodes;
+
+    void run(int64_t n, const double *verts, int leaf_size) {
+        leaf_target = std::max(1, std::min(leaf_size, kMaxLeaf));
+        tri_box.resize(n); centroid.resize(3 * (size_t)n); order.resize(n);
+        for (int64_t t = 0; t < n; ++t) {
+            const double *v = verts + 9 * (size_t)t;
+            Box b; b.reset();
+            for (int k = 0; k < 3; ++k) {
+                double lo = std::min({v[k], v[3 + k], v[6 + k]}), hi = std::max({v[k], v[3 + k], v[6 + k]});
+                if (!std::isfinite(lo) || !std::isfinite(hi)) { lo = -3.0e38; hi = 3.0e38; }   // never culled
+                b.lo[k] = round_down(lo); b.hi[k] = round_up(hi);
+                centroid[3 * (size_t)t + k] = (float)(0.5 * (lo + hi));
+            }
+            tri_box[t] = b; order[t] = (int32_t)t;
+        }
+        nodes.clear();
+        nodes.reserve((size_t)(2 * n / std::max(1, leaf_target)) + 16);
+        if (n > 0) build(0, (int32_t)n, 0);
+        const int32_t total = (int32_t)nodes.size();
+        for (auto &nd : nodes) if (nd.skip >= total) nd.skip = -1;
+    }
+
+    void make_leaf(int32_t idx, int32_t begin, int32_t end) { nodes[idx].tri_begin_count = (begin << 4) | (end - begin); }
+
+    void build(int32_t begin, int32_t end, int depth) {
+        const int32_t idx = (int32_t)nodes.size();
+        nodes.push_back(rt_bvh_node{});
+        Box bb; bb.reset();
+        Box cb; cb.reset();
+        for (int32_t i = begin; i < end; ++i) { bb.grow(tri_box[order[i]]); cb.grow(&centroid[3 * (size_t)order[i]]); }
+        for (int k = 0; k < 3; ++k) { nodes[idx].lo[k] = bb.lo[k]; nodes[idx].hi[k] = bb.hi[k]; }
+        nodes[idx].tri_begin_count = -1;
+        const int32_t count = end - begin;
+        bool leaf = count <= leaf_target;
+        int32_t mid = begin;
+        if (!leaf) {
+            // binned SAH over the three axes of the centroid box
+            double best_cost = INFINITY; int best_axis = -1, best_bin = -1;
+            for (int axis = 0; axis < 3; ++axis) {
+                const float c0 = cb.lo[axis], c1 = cb.hi[axis];
+                if (!(c1 > c0)) continue;
+                const float scale = (float)kBins / (c1 - c0);
+                Box bin_box[kBins]; int32_t bin_n[kBins];
+                for (int b = 0; b < kBins; ++b) { bin_box[b].reset(); bin_n[b] = 0; }
+                for (int32_t i = begin; i < end; ++i) {
+                    const int32_t t = order[i];
+                    int b = (int)((centroid[3 * (size_t)t + axis] - c0) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    bin_box[b].grow(tri_box[t]); bin_n[b]++;
+                }
+                double right_area[kBins]; int32_t right_n[kBins];
+                Box acc; acc.reset(); int32_t cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bin_box[b]); cnt += bin_n[b]; right_area[b] = acc.half_area(); right_n[b] = cnt; }
+                acc.reset(); cnt = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bin_box[b]); cnt += bin_n[b];
+                    if (cnt == 0 || right_n[b + 1] == 0) continue;
+                    const double cost = acc.half_area() * cnt + right_area[b + 1] * right_n[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+            // a leaf of up to kMaxLeaf triangles is kept when no split is cheaper than testing them all
+            // (box test = 1, triangle test = 2 in units of the parent's area)
+            if (best_axis >= 0 && count <= kMaxLeaf) {
+                const double leaf_cost = 2.0 * count * bb.half_area();
+                if (1.0 * bb.half_area() + 2.0 * best_cost >= leaf_cost && count <= 2 * leaf_target) leaf = true;
+            }
+            if (!leaf) {
+                if (best_axis >= 0 && depth <= 48) {   // deeper than that: halve the list instead (bounded depth)
+                    const float c0 = cb.lo[best_axis], scale = (float)kBins / (cb.hi[best_axis] - c0);
+                    auto it = std::partition(order.begin() + begin, order.begin() + end, [&](int32_t t) {
+                        int b = (int)((centroid[3 * (size_t)t + best_axis] - c0) * scale);
+                        b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                        return b <= best_bin;
+                    });
+                    mid = (int32_t)(it - order.begin());
+                }
+                if (mid <= begin || mid >= end) {
+                    // all centroids coincide (or binning failed): split the list in half, which keeps the
+                    // depth logarithmic; if it is short enough it becomes a leaf instead
+                    if (count <= kMaxLeaf) leaf = true;
+                    else {
+                        int axis = 0;
+                        for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+                        mid = begin + count / 2;
+                        std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end, [&](int32_t a, int32_t b) {
+                            return centroid[3 * (size_t)a + axis] < centroid[3 * (size_t)b + axis];
+                        });
+                    }
+                }
+            }
+        }
+        if (leaf) {
+            if (count > kMaxLeaf) {   // cannot happen (leaves are only made at or below kMaxLeaf), kept as a guard
+                mid = begin + count / 2; leaf = false;
+            } else {
+                make_leaf(idx, begin, end);
+                nodes[idx].skip = (int32_t)nodes.size();
+                return;
+            }
+        }
+        build(begin, mid, depth + 1);
+        build(mid, end, depth + 1);
+        nodes[idx].skip = (int32_t)nodes.size();
+    }
+};
+
+// Structural and containment checks.  Returns an empty string when the hierarchy is safe to use:
+// links only point forward and nest, leaves index [0, n_tris) and cover every triangle exactly once,
+// every leaf box contains its triangles and every box lies inside its parent's.
+inline std::string validate(int32_t n_nodes, const rt_bvh_node *nodes, int32_t n_tris, const int32_t *tri_index, const double *verts) {
+    if (n_nodes <= 0 || !nodes || !tri_index) return "empty hierarchy";
+    std::vector<uint8_t> seen((size_t)n_tris, 0);
+    struct Open { int32_t end; const rt_bvh_node *box; };
+    std::vector<Open> stack;
+    char buf[160];
+    for (int32_t i = 0; i < n_nodes; ++i) {
+        const rt_bvh_node &nd = nodes[i];
+        const int32_t end = nd.skip < 0 ? n_nodes : nd.skip;
+        if (end <= i || end > n_nodes) { snprintf(buf, sizeof buf, "node %d: skip %d does not point forward", i, nd.skip); return buf; }
+        while (!stack.empty() && stack.back().end <= i) stack.pop_back();
+        if (!stack.empty()) {
+            if (end > stack.back().end) { snprintf(buf, sizeof buf, "node %d: subtree crosses its parent's end", i); return buf; }
+            for (int k = 0; k < 3; ++k)
+                if (!(nd.lo[k] >= stack.back().box->lo[k] && nd.hi[k] <= stack.back().box->hi[k])) {
+                    snprintf(buf, sizeof buf, "node %d: box not inside its parent's", i); return buf;
+                }
+        } else if (i != 0) { snprintf(buf, sizeof buf, "node %d is not reachable from the root", i); return buf; }
+        if (nd.tri_begin_count < 0) {
+            if (end == i + 1) { snprintf(buf, sizeof buf, "inner node %d has no children", i); return buf; }
+            stack.push_back({end, &nd});
+        } else {
+            if (end != i + 1) { snprintf(buf, sizeof buf, "leaf %d: skip must be the next node", i); return buf; }
+            const int32_t first = nd.tri_begin_count >> 4, cnt = nd.tri_begin_count & 15;
+            if (cnt < 1 || first < 0 || (int64_t)first + cnt > n_tris) { snprintf(buf, sizeof buf, "leaf %d: bad triangle range", i); return buf; }
+            for (int32_t k = first; k < first + cnt; ++k) {
+                const int32_t t = tri_index[k];
+                if (t < 0 || t >= n_tris || seen[t]) { snprintf(buf, sizeof buf, "leaf %d: triangle %d out of range or listed twice", i, t); return buf; }
+                seen[t] = 1;
+                const double *v = verts + 9 * (size_t)t;
+                for (int c = 0; c < 9; ++c) {
+                    if (!std::isfinite(v[c])) continue;   // such a triangle can never be hit
+                    if (!(v[c] >= (double)nd.lo[c % 3] && v[c] <= (double)nd.hi[c % 3])) {
+                        snprintf(buf, sizeof buf, "leaf %d: triangle %d sticks out of the box", i, t); return buf;
+                    }
+                }
+            }
+        }
+    }
+    for (int32_t t = 0; t < n_tris; ++t) if (!seen[t]) { snprintf(buf, sizeof buf, "triangle %d is in no leaf", t); return buf; }
+    return std::string();
+}
+
+}  // namespace bvh
+}  // namespace rt

@@ -13,6 +13,7 @@
 // path runs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "rt_exact.h"
 #include "rt_scene.h"
 
@@ -143,25 +144,48 @@ RT_DEV TriEval tri_eval(const TriRow &T, const Ray &r) {
     return e;
 }
 
-struct Best { uint32_t k0, k1; };  // best and runner-up keys
+// ---------------------------------------------------------------------------------------------
+// Candidate sinks.  The search loops hand every primitive's (t_lo, id) to a sink; t_lo = +inf
+// means "not a candidate".
+// ---------------------------------------------------------------------------------------------
 
-RT_DEV void best_insert(Best &b, uint32_t key) {
-    b.k1 = umed3_(b.k0, b.k1, key);
-    b.k0 = umin_(b.k0, key);
-}
+// First pass, scenes of up to 4096 primitives: best and runner-up as 32-bit keys
+// (bits of t_lo with the low bits cleared) | id.  Three instructions per primitive.
+struct KeyBest {
+    uint32_t k0, k1, keep_mask, id_mask;
+    RT_DEV void init(const DevScene &S) { k0 = k1 = 0xFFFFFFFFu; id_mask = S.key_mask; keep_mask = ~S.key_mask; }
+    RT_DEV void operator()(float tl, int32_t id) {
+        const uint32_t key = (f2u(tl) & keep_mask) | (uint32_t)id;
+        k1 = umed3_(k0, k1, key);
+        k0 = umin_(k0, key);
+    }
+    RT_DEV bool any() const { return k0 < kKeyNone; }
+    RT_DEV int32_t best_id() const { return (int32_t)(k0 & id_mask); }
+    RT_DEV bool has_second() const { return k1 < kKeyNone; }
+    RT_DEV float second_lo() const { return u2f(k1 & keep_mask); }
+    RT_DEV float prune_bound() const { return kInf; }
+    RT_DEV void certain_hit(float) {}
+};
 
-// Second-pass sink.  When the first pass cannot name the hit on its own (a runner-up whose lower
-// bound is not behind the winner's upper bound, or a winner the double-precision code rejected),
-// the tables are walked once more and every candidate whose key is at or below `limit` is
-// evaluated by the exact code on the spot; the best of those under upstream's ordering (depth,
-// then object order, then face order: scene.py:23-27, mesh.py:101-110) is the hit.  A primitive
-// whose key is above `limit` has a true depth beyond a proven hit and cannot win or tie.
-struct Resolve {
-    const DevScene *S;
-    D3 o, d;
-    int32_t origin, skip;      // skip: the first-pass winner, already evaluated
-    uint32_t limit, keep_mask;
-    ExactHit e; int32_t gprim; uint64_t order;   // best so far; gprim < 0: none
+// First pass, large scenes (ids do not fit beside a usable depth in 32 bits): best (t_lo, id) and
+// the runner-up's t_lo as separate registers.  `tmax` is the smallest upper depth bound of any
+// primitive that is CERTAINLY hit; nothing that starts beyond it can be the closest hit or tie
+// with it, which is what lets the hierarchy walk skip boxes.
+struct PairBest {
+    float lo0, lo1, tmax; int32_t id0;
+    RT_DEV void init(const DevScene &) { lo0 = lo1 = tmax = kInf; id0 = -1; }
+    RT_DEV void operator()(float tl, int32_t id) {
+        const bool better = tl < lo0;
+        lo1 = better ? lo0 : min_(lo1, tl);
+        id0 = better ? id : id0;
+        lo0 = better ? tl : lo0;
+    }
+    RT_DEV bool any() const { return lo0 < kInf; }
+    RT_DEV int32_t best_id() const { return id0; }
+    RT_DEV bool has_second() const { return lo1 < kInf; }
+    RT_DEV float second_lo() const { return lo1; }
+    RT_DEV float prune_bound() const { return tmax; }
+    RT_DEV void certain_hit(float thi) { tmax = min_(tmax, thi); }
 };
 
 RT_DEV uint64_t scene_order(const DevScene &S, int32_t gprim) {
@@ -169,56 +193,129 @@ RT_DEV uint64_t scene_order(const DevScene &S, int32_t gprim) {
     return ((uint64_t)(uint32_t)obj << 32) | (uint32_t)gprim;
 }
 
-RT_DEV void resolve_insert(Resolve &R, uint32_t key) {
-    if (key <= R.limit) {
-        const DevScene &S = *R.S;
-        const int32_t g = (int32_t)(key & S.key_mask);
-        if (g != R.skip) {
-            const ExactHit x = exact_single(S, g, R.o, R.d, R.origin);
+// Second pass.  When the first pass cannot name the hit on its own (a runner-up whose lower bound is
+// not behind the winner's upper bound, or a winner the double-precision code rejected), the tables
+// are walked once more and every candidate whose t_lo is at or below `limit` is evaluated by the
+// exact code on the spot; the best of those under upstream's ordering (depth, then object order,
+// then face order: scene.py:23-27, mesh.py:101-110) is the hit.  A primitive whose t_lo is above
+// `limit` has a true depth beyond a proven hit and cannot win or tie.
+struct Resolve {
+    const DevScene *S;
+    D3 o, d;
+    int32_t origin, skip;      // skip: the first-pass winner, already evaluated
+    float limit;
+    ExactHit e; int32_t gprim; uint64_t order;   // best so far; gprim < 0: none
+    RT_DEV void operator()(float tl, int32_t g) {
+        if (tl <= limit && g != skip) {
+            const ExactHit x = exact_single(*S, g, o, d, origin);
             if (x.hit) {
-                const uint64_t ord = scene_order(S, g);
-                if (R.gprim < 0 || x.t < R.e.t || (x.t == R.e.t && ord < R.order)) {
-                    R.e = x; R.gprim = g; R.order = ord;
-                    const float up = (float)x.t * (1.0f + 2.0f * kU);   // >= x.t
-                    const uint32_t lim = (f2u(up) & R.keep_mask) | S.key_mask;
-                    R.limit = umin_(R.limit, lim);
+                const uint64_t ord = scene_order(*S, g);
+                if (gprim < 0 || x.t < e.t || (x.t == e.t && ord < order)) {
+                    e = x; gprim = g; order = ord;
+                    limit = min_(limit, (float)x.t * (1.0f + 2.0f * kU));   // >= x.t
                 }
             }
         }
     }
-}
+    RT_DEV float prune_bound() const { return limit; }
+    RT_DEV void certain_hit(float) {}
+};
 
-struct BestSink { Best b; RT_DEV void operator()(uint32_t key) { best_insert(b, key); } };
-struct ResolveSink { Resolve R; RT_DEV void operator()(uint32_t key) { resolve_insert(R, key); } };
-
-RT_DEV uint32_t tri_key(const TriRow &T, const Ray &r, uint32_t keep_mask) {
+// Lower bound on the depth of triangle row T for ray r, +inf when T cannot be hit.  `sure_thi`
+// (optional) receives an upper bound on the depth when the hit is certain, else +inf.
+template <bool WANT_SURE>
+RT_DEV float tri_tlo(const TriRow &T, const Ray &r, float *sure_thi) {
     TriEval e = tri_eval(T, r);
-    float mp = fma_(e.g, T.cb, e.m);
+    const float bb = e.g * T.cb;
+    float mp = e.m + bb;
     float thi = fma_(e.g, T.ct, e.t);
     float tlo = fma_(-e.g, T.ct, e.t);
     float x = min_(mp, thi);
     float y = x * (-kInf);                 // x < 0 -> +inf (not a candidate); x >= 0 -> -inf / NaN
     float tl = max_(max_(tlo, 0.0f), y);   // NaNs drop out of max: a NaN anywhere keeps the candidate
-    uint32_t key = (f2u(tl) & keep_mask) | (uint32_t)T.gprim;
     // det_lo = +inf marks the padding rows at the end of the table: never candidates (NaN included)
     const bool kill = (T.gprim == r.origin) || !(abs_(e.nd) >= T.det_lo);
-    return kill ? 0xFFFFFFFFu : key;
+    if (WANT_SURE) {
+        // certainly inside, certainly in front of the origin, certainly past upstream's |det| cut
+        // (1e-6 plus the 16 u |N| rounding allowance of N.d; ct = 1.01 |N|)
+        const bool sure = !kill && (e.m - bb >= 0.0f) && (tlo > kTCertain) && (abs_(e.nd) >= fma_(16.0f * kU, T.ct, 1.0001e-6f));
+        *sure_thi = sure ? thi : kInf;
+    }
+    return kill ? kInf : tl;
 }
 
 // Brute-force loop over the live triangles, two rows per trip.  The table is padded with dead rows
 // to an even count plus two, so the loop needs no tail and may read one trip ahead: each row's
 // scalar load is issued a full test (~37 vector instructions) before the row is used.
 template <class Sink>
-RT_DEV void search_tris(const DevScene &S, const Ray &r, Sink &sink, uint32_t keep_mask) {
+RT_DEV void search_tris(const DevScene &S, const Ray &r, Sink &sink) {
     const int n = S.n_tri_rows_padded;   // even; rows [n, n+2) exist and are dead
     if (n <= 0) return;
     const TriRow *rows = S.tri_rows;
     TriRow a0 = load_tri_row_uniform(rows, 0), a1 = load_tri_row_uniform(rows, 1);
     for (int i = 0; i < n; i += 2) {
-        sink(tri_key(a0, r, keep_mask));
+        sink(tri_tlo<false>(a0, r, nullptr), a0.gprim);
         a0 = load_tri_row_uniform(rows, i + 2);
-        sink(tri_key(a1, r, keep_mask));
+        sink(tri_tlo<false>(a1, r, nullptr), a1.gprim);
         a1 = load_tri_row_uniform(rows, i + 3);
+    }
+}
+
+// Per-lane row load (hierarchy leaves: every lane is somewhere else in the table).
+RT_DEV TriRow load_tri_row_lane(const TriRow *rows, int i) {
+    const f4 *q = (const f4 *)(rows + i);
+    f4 a = q[0], b = q[1], c = q[2], d = q[3];
+    TriRow T;
+    T.nx = a.x; T.ny = a.y; T.nz = a.z; T.kn = a.w;
+    T.e1x = b.x; T.e1y = b.y; T.e1z = b.z; T.k1 = b.w;
+    T.e2x = c.x; T.e2y = c.y; T.e2z = c.z; T.k2 = c.w;
+    T.cb = d.x; T.ct = d.y; T.det_lo = d.z;
+    const float id_bits = d.w;
+    T.gprim = (int32_t)f2u(id_bits);
+    return T;
+}
+
+// Stackless walk of the threaded hierarchy (node layout: rt_bvh_node).  Conservative slab test: the
+// computed entry/exit parameters carry a relative error of at most 5 u, which moves a box plane by
+// at most 5 u |plane - o| <= 5 u (S + |o|) (S = scene radius); rounding the ray origin, the stored
+// planes and o +- pad adds less than 3 u (S + |o|).  So every box is widened per ray by
+// pad = 10 u (S + |o|) - folded into the origin, at no cost per node - and plain comparisons can
+// then never drop a box the exact ray touches.  A NaN slab value (0 x inf: origin exactly on a box plane, direction component zero) drops out of
+// min/max and leaves that slab unconstrained.  A box is skipped when the ray misses it or enters it
+// beyond the sink's bound.
+struct BvhCounters { uint32_t nodes, tris; };
+
+template <class Sink>
+RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters &bc) {
+    const float ix = rcp_(r.dx), iy = rcp_(r.dy), iz = rcp_(r.dz);
+    const float pad = 10.0f * kU * (r.o2 + S.scene_radius);
+    const float oxp = r.ox + pad, oyp = r.oy + pad, ozp = r.oz + pad;   // subtracted from the low planes
+    const float oxm = r.ox - pad, oym = r.oy - pad, ozm = r.oz - pad;   // subtracted from the high planes
+    const f4 *nodes = (const f4 *)S.bvh_nodes;
+    const TriRow *rows = S.tri_rows;
+    int node = S.n_bvh_nodes > 0 ? 0 : -1;
+    while (node >= 0) {
+        const f4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
+        const float skip_bits = a.w, leaf_bits = b.w;
+        const int32_t skip = (int32_t)f2u(skip_bits), leaf = (int32_t)f2u(leaf_bits);
+        const float x0 = (a.x - oxp) * ix, x1 = (b.x - oxm) * ix;
+        const float y0 = (a.y - oyp) * iy, y1 = (b.y - oym) * iy;
+        const float z0 = (a.z - ozp) * iz, z1 = (b.z - ozm) * iz;
+        const float tn = max_(max_(min_(x0, x1), min_(y0, y1)), max_(min_(z0, z1), 0.0f));
+        const float tf = min_(min_(max_(x0, x1), max_(y0, y1)), min_(max_(z0, z1), sink.prune_bound()));
+        bc.nodes++;
+        if (!(tn <= tf)) { node = skip; continue; }
+        if (leaf < 0) { node = node + 1; continue; }
+        const int first = leaf >> 4, cnt = leaf & 15;
+        bc.tris += (uint32_t)cnt;
+        for (int k = 0; k < cnt; ++k) {
+            const TriRow T = load_tri_row_lane(rows, first + k);
+            float sure_thi;
+            const float tl = tri_tlo<true>(T, r, &sure_thi);
+            sink.certain_hit(sure_thi);
+            sink(tl, T.gprim);
+        }
+        node = skip;
     }
 }
 
@@ -274,7 +371,7 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
 }
 
 template <class Sink>
-RT_DEV void search_spheres(const DevScene &S, const Ray &r, Sink &sink, uint32_t keep_mask) {
+RT_DEV void search_spheres(const DevScene &S, const Ray &r, Sink &sink) {
     const int n = S.n_sph_rows;
     const SphRow *rows = S.sph_rows;
 #pragma unroll 2
@@ -301,21 +398,19 @@ RT_DEV void search_spheres(const DevScene &S, const Ray &r, Sink &sink, uint32_t
                 tl = t1lo;
             }
             tl = max_(tl, 0.0f) * (1.0f - 8.0f * kU);
-            uint32_t key = valid ? ((f2u(tl) & keep_mask) | (uint32_t)P.gprim) : 0xFFFFFFFFu;
-            sink(key);
+            sink(valid ? tl : kInf, P.gprim);
         }
     }
 }
 
 // The few huge spheres: double precision throughout.
 template <class Sink>
-RT_DEV void search_big_spheres(const DevScene &S, const Ray &r, D3 o64, D3 d64, Sink &sink, uint32_t keep_mask) {
+RT_DEV void search_big_spheres(const DevScene &S, const Ray &r, D3 o64, D3 d64, Sink &sink) {
     for (int i = 0; i < S.n_big_sph; ++i) {
         int si = S.big_sph[i];
         ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
         float tl = (float)eb.t * (1.0f - 4.0f * kU);
-        uint32_t key = eb.hit ? ((f2u(tl) & keep_mask) | (uint32_t)si) : 0xFFFFFFFFu;
-        sink(key);
+        sink(eb.hit ? tl : kInf, si);
     }
 }
 
@@ -354,7 +449,7 @@ struct Hit {
     int32_t how;                // 0 float32 filter alone, 1 winner re-evaluated in double, 2 exact scene scan
 };
 
-struct HitCounters { uint32_t exact, refine; };
+struct HitCounters { uint32_t exact, refine, bvh_nodes, bvh_tris; };
 
 // The exact code's view of a ray.  Bounce rays and caller-supplied rays ARE their float32 values.
 // A pinhole camera ray is the float32 rounding of the ray upstream computes in double precision
@@ -366,14 +461,17 @@ struct RayResidue { const float *table; uint32_t pixel; float ox, oy, oz; };
 
 RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r.ox = r.oy = r.oz = 0.0f; return r; }
 
-// The rare passes live out of line: inlined, their register needs would be charged to the hot loops.
-template <bool HAS_TRI, bool HAS_SPH>
-RT_DEV void resolve_pass(const DevScene &S, const Ray &r, D3 o64, D3 d64, ResolveSink &rs) {
+// How the triangles of a scene are searched.
+enum { kTriNone = 0, kTriBrute = 1, kTriBvh = 2 };
+
+template <int TRI, bool HAS_SPH, class Sink>
+RT_DEV void search_all(const DevScene &S, const Ray &r, D3 o64, D3 d64, Sink &sink, BvhCounters &bc) {
     if (HAS_SPH) {
-        search_spheres(S, r, rs, rs.R.keep_mask);
-        search_big_spheres(S, r, o64, d64, rs, rs.R.keep_mask);
+        search_spheres(S, r, sink);
+        search_big_spheres(S, r, o64, d64, sink);
     }
-    if (HAS_TRI) search_tris(S, r, rs, rs.R.keep_mask);
+    if (TRI == kTriBrute) search_tris(S, r, sink);
+    if (TRI == kTriBvh) search_bvh(S, r, sink, bc);
 }
 
 RT_DEV void exact_scan_pass(const DevScene &S, D3 o64, D3 d64, int32_t origin, ExactHit &e, int32_t &gprim) {
@@ -386,7 +484,7 @@ RT_DEV void exact_scan_pass(const DevScene &S, D3 o64, D3 d64, int32_t origin, E
 
 // `e64`, when given, receives the double-precision record whenever the exact code produced the hit
 // (e64->hit says whether it did).
-template <bool HAS_TRI, bool HAS_SPH, bool STRICT>
+template <int TRI, bool HAS_SPH, bool STRICT>
 RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactHit *e64, const RayResidue rr) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
     // only the rare double-precision branches below read these; the loads and conversions sink into them
@@ -398,22 +496,25 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
     const D3 o64 = d3((double)r.ox + (double)rox, (double)r.oy + (double)roy, (double)r.oz + (double)roz);
     const D3 d64 = d3((double)r.dx + (double)rdx, (double)r.dy + (double)rdy, (double)r.dz + (double)rdz);
     ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
+    BvhCounters bc; bc.nodes = 0; bc.tris = 0;
     bool scan = ray_needs_exact(r);
+    bool second = false; float limit = kInf; int32_t skip = -1;
     int32_t gprim = -1; int root = 0; float t = kInf;
-    if (!scan) {
-        const uint32_t keep_mask = ~S.key_mask;
-        BestSink first; first.b.k0 = 0xFFFFFFFFu; first.b.k1 = 0xFFFFFFFFu;
-        if (HAS_SPH) {
-            search_spheres(S, r, first, keep_mask);
-            search_big_spheres(S, r, o64, d64, first, keep_mask);
-        }
-        if (HAS_TRI) search_tris(S, r, first, keep_mask);
-        const Best b = first.b;
-        bool second = false; uint32_t limit = 0; int32_t skip = -1;
-        if (b.k0 < kKeyNone) {
-            gprim = (int32_t)(b.k0 & S.key_mask);
-            const float second_lo = u2f(b.k1 & keep_mask);
-            const bool has_second = b.k1 < kKeyNone;
+    if (TRI == kTriBvh) {
+        // A ray with a zero direction component is within the hierarchy walk's reach (see search_bvh),
+        // and a double-precision scan of a million triangles by one lane would stall its whole wave
+        // for a long time, so it is settled by the second pass with every candidate open instead.
+        const bool len_ok = (r.a >= 0.25f) && (r.a <= 4.0f) && (r.o2 < 1e18f);
+        if (scan && len_ok) { scan = false; second = true; }
+    }
+    if (!scan && !second) {
+        typename std::conditional<TRI == kTriBvh, PairBest, KeyBest>::type first;
+        first.init(S);
+        search_all<TRI, HAS_SPH>(S, r, o64, d64, first, bc);
+        if (first.any()) {
+            gprim = first.best_id();
+            const float second_lo = first.second_lo();
+            const bool has_second = first.has_second();
             int status; float thi;
             if (gprim < S.n_spheres) {
                 SphVerdict v = judge_sphere(S, gprim, r, STRICT ? kRelAcceptStrict : kRelAcceptRender);
@@ -437,31 +538,31 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
             }
             if (status == 2 && !e.hit) {
                 // the winner was not a hit after all: every other candidate is open
-                second = has_second; limit = kKeyNone - 1u; gprim = -1;
+                second = has_second; limit = kInf; gprim = -1;
             } else if (has_second && !(second_lo > thi)) {
                 // someone else may be in front, or tie: the contenders are settled in double precision
-                second = true; limit = (f2u(thi) & keep_mask) | S.key_mask;
+                second = true; limit = thi;
                 if (!e.hit) e = exact_single(S, gprim, o64, d64, r.origin);
-                if (!e.hit) { limit = kKeyNone - 1u; gprim = -1; }   // cannot happen for a certain winner; stay safe
+                if (!e.hit) { limit = kInf; gprim = -1; }   // cannot happen for a certain winner; stay safe
             }
         }
-        if (second) {
-            cnt.exact++;
-            h.how = 2;
-            ResolveSink rs;
-            rs.R.S = &S; rs.R.o = o64; rs.R.d = d64; rs.R.origin = r.origin; rs.R.skip = skip;
-            rs.R.limit = limit; rs.R.keep_mask = keep_mask;
-            rs.R.e = e; rs.R.gprim = gprim; rs.R.order = gprim >= 0 ? scene_order(S, gprim) : 0;
-            resolve_pass<HAS_TRI, HAS_SPH>(S, r, o64, d64, rs);
-            e = rs.R.e; gprim = rs.R.gprim;
-            if (gprim < 0) e.hit = false;
-        }
+    }
+    if (second) {
+        cnt.exact++;
+        h.how = 2;
+        Resolve R;
+        R.S = &S; R.o = o64; R.d = d64; R.origin = r.origin; R.skip = skip; R.limit = limit;
+        R.e = e; R.gprim = gprim; R.order = gprim >= 0 ? scene_order(S, gprim) : 0;
+        search_all<TRI, HAS_SPH>(S, r, o64, d64, R, bc);
+        e = R.e; gprim = R.gprim;
+        if (gprim < 0) e.hit = false;
     }
     if (scan) {   // upstream's Scene.intersect, literally, in double precision
         cnt.exact++;
         h.how = 2;
         exact_scan_pass(S, o64, d64, r.origin, e, gprim);
     }
+    cnt.bvh_nodes += bc.nodes; cnt.bvh_tris += bc.tris;
     if (e64) *e64 = e;
     if (gprim < 0) return h;
     h.gprim = gprim;

@@ -229,11 +229,11 @@ struct StepCounters { uint32_t sky, shaded; };
 
 // One segment: closest hit, then environment or one bounce.  Returns true while the path goes on;
 // when it returns false (er, eg, eb) is the terminal radiance to be multiplied by (tr, tg, tb).
-template <bool HAS_TRI, bool HAS_SPH>
+template <int TRI, bool HAS_SPH>
 RT_DEV bool path_step(const DevScene &S, Path &p, int max_bounces, HitCounters &cnt, StepCounters &sc,
                       float &er, float &eg, float &eb, Hit *hit_out) {
     Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0);
-    Hit h = closest_hit<HAS_TRI, HAS_SPH, false>(S, ray, cnt, nullptr, p.rr);
+    Hit h = closest_hit<TRI, HAS_SPH, false>(S, ray, cnt, nullptr, p.rr);
     if (hit_out) *hit_out = h;
     er = eg = eb = 0.0f;
     if (h.obj < 0) {
@@ -264,7 +264,7 @@ RT_DEV uint32_t rank_in(unsigned long long mask) {
 
 constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at a time
 
-template <bool HAS_TRI, bool HAS_SPH>
+template <int TRI, bool HAS_SPH>
 __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const RenderArgs A) {
     // wave-uniform job window
     uint32_t win_next = 0, win_end = 0;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
     p.depth = 0; p.origin = -1; p.inside = false;
     p.rr = no_residue();
     uint32_t n_rays = 0, n_paths = 0;
-    HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
+    HitCounters cnt; cnt.exact = 0; cnt.refine = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0;
     StepCounters sc; sc.sky = 0; sc.shaded = 0;
     const uint32_t rect_px = (uint32_t)(A.rect_w * A.rect_h);
 
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
             // ---- 3. one path segment ----------------------------------------------------------
             n_rays++;
             float er, eg, eb;
-            bool alive = path_step<HAS_TRI, HAS_SPH>(S, p, A.max_bounces, cnt, sc, er, eg, eb, nullptr);
+            bool alive = path_step<TRI, HAS_SPH>(S, p, A.max_bounces, cnt, sc, er, eg, eb, nullptr);
             if (!alive) {
                 ar = fma_(p.tr, er, ar); ag = fma_(p.tg, eg, ag); ab = fma_(p.tb, eb, ab);
                 in_path = false;
@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
     v[kStatRays] = n_rays; v[kStatPaths] = n_paths; v[kStatExact] = cnt.exact; v[kStatRefine] = cnt.refine;
     v[kStatSky] = sc.sky; v[kStatShaded] = sc.shaded;
     v[kStatSphTests] = (unsigned long long)n_rays * (uint32_t)(S.n_sph_rows + S.n_big_sph);
-    v[kStatTriTests] = (unsigned long long)n_rays * (uint32_t)S.n_tri_rows;   // dead padding rows are not counted
+    v[kStatTriTests] = TRI == kTriBvh ? (unsigned long long)cnt.bvh_tris
+                                      : (unsigned long long)n_rays * (uint32_t)S.n_tri_rows;   // dead padding rows are not counted
+    v[kStatBvhNodes] = cnt.bvh_nodes;
 #pragma unroll
     for (int i = 0; i < kStatCount; ++i) {
         unsigned long long x = v[i];
@@ -387,14 +389,14 @@ struct TraceArgs {
     float *seg_org, *seg_dir;    // [n_paths][seg_cap][3]
 };
 
-template <bool HAS_TRI, bool HAS_SPH>
+template <int TRI, bool HAS_SPH>
 __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S, const TraceArgs A) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n_paths) return;
     const int x = A.xys[3 * i], y = A.xys[3 * i + 1], smp = A.xys[3 * i + 2];
     Path p;
     path_begin(S, A.ray_dir, A.ray_res, p, (uint32_t)(x * A.height + y), (uint32_t)smp, A.seed_lo, A.seed_hi);
-    HitCounters cnt; cnt.exact = 0; cnt.refine = 0;
+    HitCounters cnt; cnt.exact = 0; cnt.refine = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0;
     StepCounters sc; sc.sky = 0; sc.shaded = 0;
     float er = 0, eg = 0, eb = 0;
     int n = 0;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S, const Tra
             A.seg_dir[3 * k] = p.dx; A.seg_dir[3 * k + 1] = p.dy; A.seg_dir[3 * k + 2] = p.dz;
         }
         Hit h;
-        bool alive = path_step<HAS_TRI, HAS_SPH>(S, p, A.max_bounces, cnt, sc, er, eg, eb, &h);
+        bool alive = path_step<TRI, HAS_SPH>(S, p, A.max_bounces, cnt, sc, er, eg, eb, &h);
         if (n < A.seg_cap) { A.seg_obj[k] = h.obj; A.seg_prim[k] = h.prim; A.seg_how[k] = h.how; A.seg_t[k] = h.t; }
         n++;
         if (!alive) break;

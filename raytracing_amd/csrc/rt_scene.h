@@ -80,6 +80,7 @@ struct DevScene {
     const int32_t *sph_obj;                           // [n_spheres]
     const MatRow *materials;                          // [n_objects]
     const ColdScene *cold;                            // device memory
+    const BvhNode *bvh_nodes; int32_t n_bvh_nodes;    // threaded hierarchy over tri_rows (then in leaf order); 0 = none
     int32_t n_spheres;
     float scene_radius;       // bound on the distance from the world origin of every vertex, small-sphere point and the camera
     uint32_t key_mask;        // low bits of a hit key that hold the primitive id

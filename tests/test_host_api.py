@@ -178,3 +178,51 @@ def test_render_result_views():
     r.update_views()
     assert tuple(r.img_arr[1, 0]) == (1, 2, 3) and tuple(r.img_arr_clipped[1, 0]) == (1, 1, 1)
     assert r.rendered_pixels == 1 and r.progress == pytest.approx(1 / 12 / 2)
+
+
+def test_native_bvh_builder_output_is_a_valid_hierarchy():
+    """rt_build_bvh runs on the CPU (no GPU needed): every triangle in exactly one leaf, boxes
+    contain their triangles and nest, links point forward - checked by an independent numpy
+    restatement of the acceptance rules."""
+    from raytracing_amd.backend.bvh import NODE_DTYPE, build_flat_bvh, check_flat_bvh
+
+    base = h.packed_scene("room_horse")
+    for levels, leaf in ((0, 4), (0, 1), (3, 4), (3, 15)):
+        sc = base.with_subdivided_mesh(base.n_meshes - 1, levels)
+        assert sc.n_tris == 22 + 288 * 4 ** levels
+        nodes, order = build_flat_bvh(sc.tri_verts, leaf_size=leaf)
+        assert nodes.dtype == NODE_DTYPE and sorted(order.tolist()) == list(range(sc.n_tris))
+        check_flat_bvh(nodes, order, sc.tri_verts)
+        leaves = nodes["tri"] >= 0
+        assert (nodes["tri"][leaves] & 15).max() <= 15 and int(leaves.sum()) * 2 - 1 == len(nodes)   # binary tree
+    # degenerate input: coincident centroids, zero-area and non-finite triangles still give a valid tree
+    tv = np.zeros((40, 9))
+    tv[:, 3] = 1.0; tv[:, 7] = 1.0
+    tv[5] = 0.0
+    tv[6, 4] = np.inf
+    nodes, order = build_flat_bvh(tv)
+    assert sorted(order.tolist()) == list(range(40)) and len(nodes) >= 1
+    # the checker itself rejects a broken tree
+    bad = nodes.copy()
+    bad["skip"][0] = 0
+    with pytest.raises(ValueError):
+        check_flat_bvh(bad, order, np.where(np.isfinite(tv), tv, 0.0))
+
+
+def test_subdivision_keeps_the_surface():
+    """Midpoint subdivision: 4x the faces per level, same total area, same bounding box."""
+    base = h.packed_scene("room_horse")
+    m = base.n_meshes - 1
+
+    def area(tv):
+        t = tv.reshape(-1, 3, 3)
+        return 0.5 * np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1).sum()
+
+    fine = base.with_subdivided_mesh(m, 2)
+    b0, b1 = base.mesh_tri_begin[m], base.mesh_tri_begin[m + 1]
+    f0, f1 = fine.mesh_tri_begin[m], fine.mesh_tri_begin[m + 1]
+    assert f1 - f0 == 16 * (b1 - b0) and fine.mesh_tri_begin[-1] == fine.n_tris
+    assert abs(area(fine.tri_verts[f0:f1]) - area(base.tri_verts[b0:b1])) < 1e-12
+    assert np.array_equal(fine.tri_verts[:f0], base.tri_verts[:b0])
+    v = fine.tri_verts[f0:f1].reshape(-1, 3)
+    assert np.all(v.min(0) >= base.mesh_aabb[m][:3]) and np.all(v.max(0) <= base.mesh_aabb[m][3:])

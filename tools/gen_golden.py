@@ -111,11 +111,21 @@ def build_scene(which: str):
     import io
 
     with contextlib.redirect_stdout(io.StringIO()):  # random_spheres prints per sphere
-        if which == "room":
+        if which in ("room", "room_horse"):
             import scenes.room as mod
         else:
             import scenes.random_spheres as mod
         scene = mod.get_scene()
+        if which == "room_horse":
+            # room plus upstream's other model asset (288 faces), placed with upstream's own setters
+            from src.core import Vec3
+            from src.mesh import Mesh
+
+            for m in Mesh.load_from_obj_file("./assets/models/obj/chess_horse.obj"):
+                m.set_scale(Vec3(0.32))
+                m.set_rotation(Vec3(0, 35, 0))
+                m.set_origin(Vec3(0.45, -1.0, 0.25))
+                scene.add_object(m)
     return scene
 
 
@@ -259,13 +269,13 @@ def cmd_scenes():
 
     os.makedirs(GOLD, exist_ok=True)
     sky_saved = False
-    for which in ("room", "random_spheres"):
+    for which in ("room", "random_spheres", "room_horse"):
         scene = build_scene(which)
         p = pack_scene(scene, build_bvh=False)
         if not sky_saved:
             np.savez_compressed(os.path.join(GOLD, "skybox1_rgb8.npz"), rgb=p.sky_rgb)
             sky_saved = True
-        name = "room" if which == "room" else f"random_spheres_seed{SEED_SCENE}"
+        name = which if which != "random_spheres" else f"random_spheres_seed{SEED_SCENE}"
         p.save(os.path.join(GOLD, f"scene_{name}.npz"), with_sky=False)
         print(which, "objects", p.n_objects, "spheres", p.n_spheres, "tris", p.n_tris, "sky_scale", p.sky_scale)
 
@@ -351,9 +361,9 @@ def _recs_to_npz(recs, path, meta):
         s=arr("s", np.int32), seg=arr("seg", np.int32), meta=np.array(json.dumps(meta)))
 
 
-def cmd_rays():
+def cmd_rays(cases=(("room", 96, 54, 2, 8, 1), ("random_spheres", 96, 54, 4, 8, 1))):
     """Per-segment ray dumps: every Scene.intersect call of a few thousand seeded paths."""
-    for which, W, H, spp, bounces, stride in (("room", 96, 54, 2, 8, 1), ("random_spheres", 96, 54, 4, 8, 1)):
+    for which, W, H, spp, bounces, stride in cases:
         t0 = time.time()
         xs = list(range(0, W, stride))
         out, status, ndraws, recs = render_paths(which, W, H, spp, bounces, xs, record_rays=True)
@@ -377,7 +387,7 @@ def cmd_image(which, W, H, spp, bounces, procs, tag):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["kat", "scenes", "rays", "room_image", "spheres_image", "all"])
+    ap.add_argument("what", choices=["kat", "scenes", "rays", "rays_horse", "room_image", "spheres_image", "all"])
     ap.add_argument("--procs", type=int, default=6)
     a = ap.parse_args()
     if a.what in ("scenes", "all"):
@@ -386,6 +396,8 @@ def main():
         cmd_kat()
     if a.what in ("rays", "all"):
         cmd_rays()
+    if a.what in ("rays_horse", "all"):
+        cmd_rays(cases=(("room_horse", 64, 36, 1, 6, 1),))
     if a.what in ("room_image", "all"):
         cmd_image("room", 96, 54, 8, 8, a.procs, "room_96x54_8spp_8b")
     if a.what in ("spheres_image", "all"):
