@@ -294,28 +294,37 @@ RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters 
     const f4 *nodes = (const f4 *)S.bvh_nodes;
     const TriRow *rows = S.tri_rows;
     int node = S.n_bvh_nodes > 0 ? 0 : -1;
-    while (node >= 0) {
-        const f4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
-        const float skip_bits = a.w, leaf_bits = b.w;
-        const int32_t skip = (int32_t)f2u(skip_bits), leaf = (int32_t)f2u(leaf_bits);
-        const float x0 = (a.x - oxp) * ix, x1 = (b.x - oxm) * ix;
-        const float y0 = (a.y - oyp) * iy, y1 = (b.y - oym) * iy;
-        const float z0 = (a.z - ozp) * iz, z1 = (b.z - ozm) * iz;
-        const float tn = max_(max_(min_(x0, x1), min_(y0, y1)), max_(min_(z0, z1), 0.0f));
-        const float tf = min_(min_(max_(x0, x1), max_(y0, y1)), min_(max_(z0, z1), sink.prune_bound()));
-        bc.nodes++;
-        if (!(tn <= tf)) { node = skip; continue; }
-        if (leaf < 0) { node = node + 1; continue; }
+    // Two nested loops ("while-while"): every lane first walks boxes until it stands on a leaf, then
+    // the lanes test their leaves' triangles together.  With a single loop the few lanes that are on
+    // a leaf at any moment would make the whole wave run the triangle code on every trip.
+    for (;;) {
+        int32_t leaf = -1;
+        while (node >= 0) {
+            const f4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
+            const float skip_bits = a.w, leaf_bits = b.w;
+            const int32_t skip = (int32_t)f2u(skip_bits), info = (int32_t)f2u(leaf_bits);
+            const float x0 = (a.x - oxp) * ix, x1 = (b.x - oxm) * ix;
+            const float y0 = (a.y - oyp) * iy, y1 = (b.y - oym) * iy;
+            const float z0 = (a.z - ozp) * iz, z1 = (b.z - ozm) * iz;
+            const float tn = max_(max_(min_(x0, x1), min_(y0, y1)), max_(min_(z0, z1), 0.0f));
+            const float tf = min_(min_(max_(x0, x1), max_(y0, y1)), min_(max_(z0, z1), sink.prune_bound()));
+            bc.nodes++;
+            const bool hit = tn <= tf;
+            if (hit && info >= 0) { leaf = info; node = skip; break; }
+            node = hit ? node + 1 : skip;
+        }
+        if (leaf < 0) break;
         const int first = leaf >> 4, cnt = leaf & 15;
         bc.tris += (uint32_t)cnt;
+        TriRow T = load_tri_row_lane(rows, first);
         for (int k = 0; k < cnt; ++k) {
-            const TriRow T = load_tri_row_lane(rows, first + k);
+            const TriRow cur = T;
+            if (k + 1 < cnt) T = load_tri_row_lane(rows, first + k + 1);   // in flight while `cur` is tested
             float sure_thi;
-            const float tl = tri_tlo<true>(T, r, &sure_thi);
+            const float tl = tri_tlo<true>(cur, r, &sure_thi);
             sink.certain_hit(sure_thi);
-            sink(tl, T.gprim);
+            sink(tl, cur.gprim);
         }
-        node = skip;
     }
 }
 
