@@ -410,15 +410,16 @@ __global__ __launch_bounds__(256) void k_intersect(const DevScene S, const Isect
     const bool f32_ray = (double)fox == ox && (double)foy == oy && (double)foz == oz && (double)fdx == dx &&
                          (double)fdy == dy && (double)fdz == dz;
     ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
-    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.how = 2;
-    HitCounters cnt; cnt.exact = 0; cnt.refine = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0;
+    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.how = 2; h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0;
+    bool did_exact = false;
     if (f32_ray) {
         Ray r = make_ray(S, fox, foy, foz, fdx, fdy, fdz, origin, false);
-        h = closest_hit<TRI, HAS_SPH, true>(S, r, cnt, &e, no_residue());
+        h = closest_hit<TRI, HAS_SPH, true>(S, r, &e, no_residue());
+        did_exact = h.how == 2;
     } else {
         const D3 o64 = d3(ox, oy, oz), d64 = d3(dx, dy, dz);
         ScanHit sh = exact_scan(S, o64, d64, origin);
-        cnt.exact = 1;
+        did_exact = true;
         if (sh.gprim >= 0) e = exact_single(S, sh.gprim, o64, d64, origin);
         if (e.hit) {
             h.gprim = sh.gprim;
@@ -442,8 +443,8 @@ __global__ __launch_bounds__(256) void k_intersect(const DevScene S, const Isect
         A.pos[3 * i + 1] = !hit ? 0.0 : (have64 ? e.pos.y : (double)h.py);
         A.pos[3 * i + 2] = !hit ? 0.0 : (have64 ? e.pos.z : (double)h.pz);
     }
-    if (cnt.exact) atomicAdd(A.stats + kStatExact, (unsigned long long)cnt.exact);
-    if (cnt.refine) atomicAdd(A.stats + kStatRefine, (unsigned long long)cnt.refine);
+    if (did_exact) atomicAdd(A.stats + kStatExact, 1ull);
+    if (h.refined) atomicAdd(A.stats + kStatRefine, 1ull);
 }
 
 template <class F> void dispatch_variant(int tri, bool sph, F &&f) {

@@ -455,10 +455,11 @@ RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r, floa
 struct Hit {
     int32_t obj, prim, gprim;   // obj < 0: miss
     float t, nx, ny, nz, px, py, pz;
-    int32_t how;                // 0 float32 filter alone, 1 winner re-evaluated in double, 2 exact scene scan
+    int32_t how;                // 0 float32 filter alone, 1 winner re-evaluated in double, 2 contenders / scene settled in double
+    bool refined;               // the winning primitive was re-evaluated in double precision on the way
+    uint32_t bvh_nodes, bvh_tris;   // boxes and triangles this query tested in the hierarchy (0 without one)
 };
 
-struct HitCounters { uint32_t exact, refine, bvh_nodes, bvh_tris; };
 
 // The exact code's view of a ray.  Bounce rays and caller-supplied rays ARE their float32 values.
 // A pinhole camera ray is the float32 rounding of the ray upstream computes in double precision
@@ -466,9 +467,11 @@ struct HitCounters { uint32_t exact, refine, bvh_nodes, bvh_tris; };
 // and the exact code adds it back, so that camera rays which graze an edge - with a 90 degree
 // field of view the image diagonals of the room scene run exactly along the cube's edges - resolve
 // as upstream resolves them.  `table` is null for every other ray.
-struct RayResidue { const float *table; uint32_t pixel; float ox, oy, oz; };
+// `table` and the origin residue are the same for every lane (kernel arguments); only `on` and
+// `pixel` are per-lane, and both already live in the caller's state.
+struct RayResidue { const float *table; uint32_t pixel; bool on; float ox, oy, oz; };
 
-RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r.ox = r.oy = r.oz = 0.0f; return r; }
+RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r.on = false; r.ox = r.oy = r.oz = 0.0f; return r; }
 
 // How the triangles of a scene are searched.
 enum { kTriNone = 0, kTriBrute = 1, kTriBvh = 2 };
@@ -494,11 +497,12 @@ RT_DEV void exact_scan_pass(const DevScene &S, D3 o64, D3 d64, int32_t origin, E
 // `e64`, when given, receives the double-precision record whenever the exact code produced the hit
 // (e64->hit says whether it did).
 template <int TRI, bool HAS_SPH, bool STRICT>
-RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactHit *e64, const RayResidue rr) {
+RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, ExactHit *e64, const RayResidue rr) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
+    h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0;
     // only the rare double-precision branches below read these; the loads and conversions sink into them
     float rdx = 0.0f, rdy = 0.0f, rdz = 0.0f, rox = 0.0f, roy = 0.0f, roz = 0.0f;
-    if (rr.table) {
+    if (rr.on) {
         const f4 q = *(const f4 *)(rr.table + 4 * (size_t)rr.pixel);
         rdx = q.x; rdy = q.y; rdz = q.z; rox = rr.ox; roy = rr.oy; roz = rr.oz;
     }
@@ -536,12 +540,12 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
             if (status == 1 && gprim >= S.n_spheres) {
                 // a triangle that is certainly the hit but whose float32 depth is too coarse (grazing
                 // incidence): only the depth is redone in double precision
-                cnt.refine++;
+                h.refined = true;
                 t = (float)exact_tri_depth(S.cold->tri64 + 9 * (size_t)(gprim - S.n_spheres), o64, d64);
                 thi = t * (1.0f + 2.0f * kU);
                 h.how = 1;
             } else if (status != 0) {   // undecided, or an imprecise sphere: double precision for this primitive
-                cnt.refine++;
+                h.refined = true;
                 e = exact_single(S, gprim, o64, d64, r.origin);
                 if (e.hit) { t = (float)e.t; thi = t * (1.0f + 2.0f * kU); root = e.prim; }
             }
@@ -557,7 +561,6 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
         }
     }
     if (second) {
-        cnt.exact++;
         h.how = 2;
         Resolve R;
         R.S = &S; R.o = o64; R.d = d64; R.origin = r.origin; R.skip = skip; R.limit = limit;
@@ -567,11 +570,10 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, HitCounters &cnt, ExactH
         if (gprim < 0) e.hit = false;
     }
     if (scan) {   // upstream's Scene.intersect, literally, in double precision
-        cnt.exact++;
         h.how = 2;
         exact_scan_pass(S, o64, d64, r.origin, e, gprim);
     }
-    cnt.bvh_nodes += bc.nodes; cnt.bvh_tris += bc.tris;
+    h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
     if (e64) *e64 = e;
     if (gprim < 0) return h;
     h.gprim = gprim;

@@ -142,11 +142,10 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene S, int W, int H, 
 // double precision with a Newton reciprocal square root (~1e-16 of upstream's doubles), and the
 // float32 rounding of that ray is THE ray (no residue: the jitter decorrelates edge cases anyway).
 RT_DEV void camera_ray(const DevScene &S, const float *ray_dir, const float *ray_res, uint32_t pixel, uint32_t key0,
-                       uint32_t key1, float &ox, float &oy, float &oz, float &dx, float &dy, float &dz, RayResidue &rr) {
+                       uint32_t key1, float &ox, float &oy, float &oz, float &dx, float &dy, float &dz) {
     const f4 q = *(const f4 *)(ray_dir + 4 * (size_t)pixel);
     dx = q.x; dy = q.y; dz = q.z;
     ox = S.cam_pos[0]; oy = S.cam_pos[1]; oz = S.cam_pos[2];
-    rr.table = ray_res; rr.pixel = pixel; rr.ox = S.cam_res[0]; rr.oy = S.cam_res[1]; rr.oz = S.cam_res[2];
     if (S.dof_on) {
         const double *c = S.cold->cam64;
         const f4 e = *(const f4 *)(ray_res + 4 * (size_t)pixel);
@@ -159,7 +158,6 @@ RT_DEV void camera_ray(const DevScene &S, const float *ray_dir, const float *ray
         const double s = rsqrt64(tx * tx + ty * ty + tz * tz);
         ox = (float)oox; oy = (float)ooy; oz = (float)ooz;
         dx = (float)(tx * s); dy = (float)(ty * s); dz = (float)(tz * s);
-        rr = no_residue();
     }
 }
 
@@ -215,38 +213,37 @@ struct Path {
     int32_t depth;                  // closest-hit queries done so far
     int32_t origin;                 // primitive the current ray starts on, -1 = camera
     bool inside;                    // Ray.inside (ray.py:10), toggled by refraction
-    RayResidue rr;                  // where the exact code finds the camera ray's double-precision residue
+    uint32_t pixel;                 // x * H + y: Philox key and row of the camera-ray table
 };
 
 RT_DEV void path_begin(const DevScene &S, const float *ray_dir, const float *ray_res, Path &p, uint32_t pixel,
                        uint32_t sample, uint32_t seed_lo, uint32_t seed_hi) {
     p.key0 = pixel ^ seed_lo; p.key1 = sample ^ seed_hi;
-    camera_ray(S, ray_dir, ray_res, pixel, p.key0, p.key1, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.rr);
+    camera_ray(S, ray_dir, ray_res, pixel, p.key0, p.key1, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz);
+    p.pixel = pixel;
     p.tr = p.tg = p.tb = 1.0f; p.depth = 0; p.inside = false; p.origin = -1;
 }
 
-struct StepCounters { uint32_t sky, shaded; };
 
 // One segment: closest hit, then environment or one bounce.  Returns true while the path goes on;
 // when it returns false (er, eg, eb) is the terminal radiance to be multiplied by (tr, tg, tb).
 template <int TRI, bool HAS_SPH>
-RT_DEV bool path_step(const DevScene &S, Path &p, int max_bounces, HitCounters &cnt, StepCounters &sc,
-                      float &er, float &eg, float &eb, Hit *hit_out) {
+RT_DEV bool path_step(const DevScene &S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h) {
     Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0);
-    Hit h = closest_hit<TRI, HAS_SPH, false>(S, ray, cnt, nullptr, p.rr);
-    if (hit_out) *hit_out = h;
+    // a pinhole camera ray is the rounding of a double-precision ray whose residue is in the table
+    RayResidue rr;
+    rr.table = ray_res; rr.pixel = p.pixel; rr.on = (p.depth == 0) && !S.dof_on;
+    rr.ox = S.cam_res[0]; rr.oy = S.cam_res[1]; rr.oz = S.cam_res[2];
+    h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, rr);
     er = eg = eb = 0.0f;
     if (h.obj < 0) {
         environment(S, p.dx, p.dy, p.dz, er, eg, eb);
-        sc.sky++;
         return false;
     }
-    sc.shaded++;
     const MatRow m = S.materials[h.obj];
     const Draws u = segment_draws(p.key0, p.key1, (uint32_t)p.depth + 1u);
     bool alive = shade_bounce(m, h, u, p.dx, p.dy, p.dz, p.inside, p.tr, p.tg, p.tb, er, eg, eb);
     p.ox = h.px; p.oy = h.py; p.oz = h.pz; p.origin = h.gprim;
-    p.rr = no_residue();
     p.depth++;
     if (alive && p.depth > max_bounces) { alive = false; er = eg = eb = 0.0f; }   // renderer.py:29-30
     return alive;
@@ -271,16 +268,16 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
     bool drained = false;
     // per-lane job state
     bool have_job = false, in_path = false;
-    uint32_t pixel = 0, slot = 0;
-    int px = 0, py = 0, s_cur = 0, s_end = 0;
+    uint32_t slot = 0;
+    int s_cur = 0, s_end = 0;
     float ar = 0, ag = 0, ab = 0;
     Path p;
     p.ox = p.oy = p.oz = 0; p.dx = p.dy = 0; p.dz = 1; p.tr = p.tg = p.tb = 1; p.key0 = p.key1 = 0;
-    p.depth = 0; p.origin = -1; p.inside = false;
-    p.rr = no_residue();
-    uint32_t n_rays = 0, n_paths = 0;
-    HitCounters cnt; cnt.exact = 0; cnt.refine = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0;
-    StepCounters sc; sc.sky = 0; sc.shaded = 0;
+    p.depth = 0; p.origin = -1; p.inside = false; p.pixel = 0;
+    // Statistics are kept per WAVE in scalar registers (lane counts of ballots taken where the wave
+    // is converged), not per lane: six vector registers less for the whole life of the kernel.
+    uint32_t w_rays = 0, w_paths = 0, w_exact = 0, w_refine = 0, w_sky = 0, w_shaded = 0;
+    uint32_t l_nodes = 0, l_tris = 0;   // hierarchy only: per-lane sums, reduced at the end
     const uint32_t rect_px = (uint32_t)(A.rect_w * A.rect_h);
 
     for (;;) {
@@ -301,9 +298,8 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
                 uint32_t job = win_next + r;
                 const uint32_t chunk = fast_div(job, A.div_rect_px), pl = job - chunk * rect_px;
                 const uint32_t col = fast_div(pl, A.div_rect_h);
-                px = A.x0 + (int)col;
-                py = A.y0 + (int)(pl - col * (uint32_t)A.rect_h);
-                pixel = (uint32_t)(px * A.height + py);
+                const int px = A.x0 + (int)col, py = A.y0 + (int)(pl - col * (uint32_t)A.rect_h);
+                p.pixel = (uint32_t)(px * A.height + py);
                 slot = job;
                 s_cur = A.sample_begin + (int)chunk * A.chunk_samples;
                 int lim = A.sample_begin + A.sample_count;
@@ -317,17 +313,22 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
         }
         if (__ballot(have_job) == 0) break;
 
+        const bool starting = have_job && !in_path;
+        w_paths += (uint32_t)__builtin_popcountll(__ballot(starting));
+        w_rays += (uint32_t)__builtin_popcountll(__ballot(have_job));
+        bool f_exact = false, f_refine = false, f_sky = false, f_shaded = false;
         if (have_job) {
             // ---- 2. start the next sample of this lane's pixel --------------------------------
             if (!in_path) {
-                path_begin(S, A.ray_dir, A.ray_res, p, pixel, (uint32_t)s_cur, A.seed_lo, A.seed_hi);
+                path_begin(S, A.ray_dir, A.ray_res, p, p.pixel, (uint32_t)s_cur, A.seed_lo, A.seed_hi);
                 in_path = true;
-                n_paths++;
             }
             // ---- 3. one path segment ----------------------------------------------------------
-            n_rays++;
             float er, eg, eb;
-            bool alive = path_step<TRI, HAS_SPH>(S, p, A.max_bounces, cnt, sc, er, eg, eb, nullptr);
+            Hit h;
+            bool alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h);
+            f_exact = h.how == 2; f_refine = h.refined; f_sky = h.obj < 0; f_shaded = h.obj >= 0;
+            if (TRI == kTriBvh) { l_nodes += h.bvh_nodes; l_tris += h.bvh_tris; }
             if (!alive) {
                 ar = fma_(p.tr, er, ar); ag = fma_(p.tg, eg, ag); ab = fma_(p.tb, eb, ab);
                 in_path = false;
@@ -337,27 +338,33 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
                         float *dst = A.partial + 3 * (size_t)slot;
                         dst[0] = ar; dst[1] = ag; dst[2] = ab;
                     } else {
-                        float *dst = A.accum + 3 * (size_t)pixel;
+                        float *dst = A.accum + 3 * (size_t)p.pixel;
                         dst[0] += ar; dst[1] += ag; dst[2] += ab;
                     }
                     have_job = false;
                 }
             }
         }
+        w_exact += (uint32_t)__builtin_popcountll(__ballot(f_exact));
+        w_refine += (uint32_t)__builtin_popcountll(__ballot(f_refine));
+        w_sky += (uint32_t)__builtin_popcountll(__ballot(f_sky));
+        w_shaded += (uint32_t)__builtin_popcountll(__ballot(f_shaded));
     }
     // ---- statistics: one atomic per counter per wave ------------------------------------------
-    unsigned long long v[kStatCount] = {0};
-    v[kStatRays] = n_rays; v[kStatPaths] = n_paths; v[kStatExact] = cnt.exact; v[kStatRefine] = cnt.refine;
-    v[kStatSky] = sc.sky; v[kStatShaded] = sc.shaded;
-    v[kStatSphTests] = (unsigned long long)n_rays * (uint32_t)(S.n_sph_rows + S.n_big_sph);
-    v[kStatTriTests] = TRI == kTriBvh ? (unsigned long long)cnt.bvh_tris
-                                      : (unsigned long long)n_rays * (uint32_t)S.n_tri_rows;   // dead padding rows are not counted
-    v[kStatBvhNodes] = cnt.bvh_nodes;
+    unsigned long long nodes = l_nodes, tris = l_tris;
+    if (TRI == kTriBvh) {
+        for (int off = 32; off > 0; off >>= 1) { nodes += __shfl_down(nodes, off, 64); tris += __shfl_down(tris, off, 64); }
+    }
+    if (lane_id() == 0) {
+        unsigned long long v[kStatCount] = {0};
+        v[kStatRays] = w_rays; v[kStatPaths] = w_paths; v[kStatExact] = w_exact; v[kStatRefine] = w_refine;
+        v[kStatSky] = w_sky; v[kStatShaded] = w_shaded;
+        v[kStatSphTests] = (unsigned long long)w_rays * (uint32_t)(S.n_sph_rows + S.n_big_sph);
+        v[kStatTriTests] = TRI == kTriBvh ? tris : (unsigned long long)w_rays * (uint32_t)S.n_tri_rows;   // dead padding rows are not counted
+        v[kStatBvhNodes] = nodes;
 #pragma unroll
-    for (int i = 0; i < kStatCount; ++i) {
-        unsigned long long x = v[i];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane_id() == 0 && x) atomicAdd(A.stats + i, x);
+        for (int i = 0; i < kStatCount; ++i)
+            if (v[i]) atomicAdd(A.stats + i, v[i]);
     }
 }
 
@@ -396,8 +403,6 @@ __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S, const Tra
     const int x = A.xys[3 * i], y = A.xys[3 * i + 1], smp = A.xys[3 * i + 2];
     Path p;
     path_begin(S, A.ray_dir, A.ray_res, p, (uint32_t)(x * A.height + y), (uint32_t)smp, A.seed_lo, A.seed_hi);
-    HitCounters cnt; cnt.exact = 0; cnt.refine = 0; cnt.bvh_nodes = 0; cnt.bvh_tris = 0;
-    StepCounters sc; sc.sky = 0; sc.shaded = 0;
     float er = 0, eg = 0, eb = 0;
     int n = 0;
     for (;;) {
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S, const Tra
             A.seg_dir[3 * k] = p.dx; A.seg_dir[3 * k + 1] = p.dy; A.seg_dir[3 * k + 2] = p.dz;
         }
         Hit h;
-        bool alive = path_step<TRI, HAS_SPH>(S, p, A.max_bounces, cnt, sc, er, eg, eb, &h);
+        bool alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h);
         if (n < A.seg_cap) { A.seg_obj[k] = h.obj; A.seg_prim[k] = h.prim; A.seg_how[k] = h.how; A.seg_t[k] = h.t; }
         n++;
         if (!alive) break;
