@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -60,7 +61,7 @@ struct rt_ctx {
     bool has_scene = false;
     DevScene S{};
     int tri_mode = 0; bool has_sph = false;
-    DevBuf tri_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
+    DevBuf tri_rows, quad_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
@@ -210,7 +211,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     std::vector<int> tri_mesh(d->n_tris, 0);
     for (int m = 0; m < d->n_meshes; ++m)
         for (int t = d->mesh_tri_begin[m]; t < d->mesh_tri_begin[m + 1]; ++t) tri_mesh[t] = m;
-    std::vector<TriRow> rows_live, rows_all(d->n_tris);
+    std::vector<TriRow> rows_all(d->n_tris);
     std::vector<TriAux> aux(d->n_tris);
     bool any_det = false;
     for (int t = 0; t < d->n_tris; ++t) {
@@ -239,7 +240,6 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             x.det_hi = up(1e-6 + noise);
             if (r.det_lo > 0) any_det = true;
             x.nx = (float)(N.x / nl); x.ny = (float)(N.y / nl); x.nz = (float)(N.z / nl);
-            rows_live.push_back(r);
             scene_radius = std::max({scene_radius, norm(a), norm(b), norm(cc)});
         } else {
             // never a candidate; judged "undecided" if ever asked, so the exact code answers
@@ -286,10 +286,59 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             const double nl = (double)r.ct / 1.01;
             r.cb = up(1.01 * (2.25 * (double)r.cb * nl + 2.0 * nl / smin));
         };
-        for (auto &r : rows_live) finish(r);
         for (auto &r : rows_all) finish(r);
     }
-
+    // Linear table: live rows in triangle order.  Two triangles of one mesh that share an edge and
+    // form a parallelogram (d = a + c - b to 1e-11 of the triangle's smallest height - rectangles
+    // typed in decimal are not exact in binary) share one row: the first triangle's functionals,
+    // rebuilt for the vertex order that puts the shared edge at a-c, with both bound constants
+    // widened by 1e-3, far more than the tolerance (see row_candidates).
+    std::vector<TriRow> rows_live, rows_quad;
+    int n_live_tris = 0;
+    {
+        const bool merge_pairs = !use_bvh && std::getenv("RAYTRACING_AMD_NO_QUADS") == nullptr;   // switch for A/B runs and tests
+        std::vector<char> taken(d->n_tris, 0);
+        auto vtx = [&](int t, int k) { const double *v = d->tri_verts + 9 * (size_t)t + 3 * k; return V3{v[0], v[1], v[2]}; };
+        auto same = [](V3 p, V3 q) { return p.x == q.x && p.y == q.y && p.z == q.z; };
+        for (int t = 0; t < d->n_tris; ++t) {
+            if (taken[t] || !(rows_all[t].det_lo < INFINITY)) continue;
+            TriRow r = rows_all[t];
+            ++n_live_tris;
+            const int mesh_end = d->mesh_tri_begin[tri_mesh[t] + 1];
+            for (int y = t + 1; merge_pairs && y < std::min(mesh_end, t + 65) && n_gprim < (1 << kQuadIdBits); ++y) {
+                if (taken[y] || !(rows_all[y].det_lo < INFINITY)) continue;
+                // shared vertices (bitwise equal), and each triangle's remaining one
+                int xs = -1, ys = -1, n_shared = 0;
+                bool x_shared[3] = {false, false, false}, y_shared[3] = {false, false, false};
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+                    if (!x_shared[i] && !y_shared[j] && same(vtx(t, i), vtx(y, j))) { x_shared[i] = y_shared[j] = true; ++n_shared; }
+                if (n_shared != 2) continue;
+                for (int i = 0; i < 3; ++i) { if (!x_shared[i]) xs = i; if (!y_shared[i]) ys = i; }
+                // rotate X so that its own vertex is b: (a, b, c) = (X[xs-1], X[xs], X[xs+1])
+                const V3 a = vtx(t, (xs + 2) % 3), b = vtx(t, xs), cc = vtx(t, (xs + 1) % 3), dd = vtx(y, ys);
+                const V3 ab = sub(b, a), ac = sub(cc, a), cb_ = sub(b, cc), N = cross(ab, ac);
+                const double nl = norm(N), longest = std::max({norm(ab), norm(ac), norm(cb_)});
+                const V3 gap = {a.x + cc.x - b.x - dd.x, a.y + cc.y - b.y - dd.y, a.z + cc.z - b.z - dd.z};
+                if (!(norm(gap) <= 1e-11 * nl / longest)) continue;
+                // functionals of the rotated triangle, as in the per-triangle rows above
+                V3 e1 = cross(ac, N), e2 = cross(N, ab);
+                const double n2 = nl * nl;
+                e1 = {e1.x / n2, e1.y / n2, e1.z / n2}; e2 = {e2.x / n2, e2.y / n2, e2.z / n2};
+                r.nx = (float)N.x; r.ny = (float)N.y; r.nz = (float)N.z; r.kn = (float)(-dot(N, a));
+                r.e1x = (float)e1.x; r.e1y = (float)e1.y; r.e1z = (float)e1.z; r.k1 = (float)(-dot(e1, a));
+                r.e2x = (float)e2.x; r.e2y = (float)e2.y; r.e2z = (float)e2.z; r.k2 = (float)(-dot(e2, a));
+                const double smin = std::max(scene_radius, 1e-30);
+                r.cb = up(1.001 * 1.01 * (2.25 * (norm(e1) + norm(e2)) * nl + 2.0 * nl / smin));
+                r.ct = up(1.001 * 1.01 * nl);
+                r.det_lo = std::min(rows_all[t].det_lo, rows_all[y].det_lo);
+                r.gprim = kQuadFlag | ((d->n_spheres + y) << kQuadIdBits) | (d->n_spheres + t);
+                taken[y] = 1;
+                ++n_live_tris;
+                break;
+            }
+            ((r.gprim & kQuadFlag) ? rows_quad : rows_live).push_back(r);
+        }
+    }
     // ---- materials, environment ---------------------------------------------------------------
     std::vector<MatRow> mats(d->n_objects);
     for (int i = 0; i < d->n_objects; ++i) {
@@ -314,18 +363,20 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     std::vector<int32_t> okind(d->obj_kind, d->obj_kind + d->n_objects), oindex(d->obj_index, d->obj_index + d->n_objects);
     std::vector<int32_t> sobj(d->sphere_obj, d->sphere_obj + d->n_spheres);
     // pad the live rows with dead ones (det_lo = +inf) to an even count, plus two to read ahead
-    int n_live = (int)rows_live.size();
+    int n_live = n_live_tris;
     if (use_bvh) {   // the walk reads rows in leaf order (dead triangles included: they kill themselves)
         rows_live.resize(d->n_tris);
         for (int k = 0; k < d->n_tris; ++k) rows_live[k] = rows_all[bvh_order[k]];
         n_live = d->n_tris;
     }
-    if (n_live) {
+    const bool any_tri_rows = !rows_live.empty(), any_quad_rows = !rows_quad.empty();
+    for (auto *tab : {&rows_live, &rows_quad}) {
+        if (tab->empty()) continue;
         TriRow dead{}; dead.kn = 1; dead.k1 = dead.k2 = -1; dead.det_lo = INFINITY; dead.gprim = -2;
-        while (rows_live.size() % 2) rows_live.push_back(dead);
-        for (int k = 0; k < 2; ++k) rows_live.push_back(dead);
+        while (tab->size() % 2) tab->push_back(dead);
+        for (int k = 0; k < 2; ++k) tab->push_back(dead);
     }
-    HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
+    HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
     HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
     HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));
     HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
@@ -335,7 +386,8 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
 
     DevScene &S = c->S;
     S = DevScene{};
-    S.tri_rows = c->tri_rows.as<TriRow>(); S.n_tri_rows = n_live; S.n_tri_rows_padded = n_live ? (int)rows_live.size() - 2 : 0;
+    S.tri_rows = c->tri_rows.as<TriRow>(); S.n_tri_rows = n_live; S.n_tri_rows_padded = any_tri_rows ? (int)rows_live.size() - 2 : 0;
+    S.quad_rows = c->quad_rows.as<TriRow>(); S.n_quad_rows_padded = any_quad_rows ? (int)rows_quad.size() - 2 : 0;
     S.sph_rows = c->sph_rows.as<SphRow>(); S.n_sph_rows = (int)sph_small.size();
     S.big_sph = c->big_sph.as<int32_t>(); S.n_big_sph = (int)big.size();
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();

@@ -206,7 +206,7 @@ struct Resolve {
     float limit;
     ExactHit e; int32_t gprim; uint64_t order;   // best so far; gprim < 0: none
     RT_DEV void operator()(float tl, int32_t g) {
-        if (tl <= limit && g != skip) {
+        if (tl <= limit && tl < kInf && g != skip) {   // +inf = not a candidate (padding rows carry no valid id)
             const ExactHit x = exact_single(*S, g, o, d, origin);
             if (x.hit) {
                 const uint64_t ord = scene_order(*S, g);
@@ -244,20 +244,91 @@ RT_DEV float tri_tlo(const TriRow &T, const Ray &r, float *sure_thi) {
     return kill ? kInf : tl;
 }
 
-// Brute-force loop over the live triangles, two rows per trip.  The table is padded with dead rows
-// to an even count plus two, so the loop needs no tail and may read one trip ahead: each row's
-// scalar load is issued a full test (~37 vector instructions) before the row is used.
+// One row of the linear table.  A row is a triangle, or - flagged in its id word - a parallelogram
+// made of two triangles of one mesh that share an edge: (a, b, c) and {a, c, d} with d = a + c - b.
+// The pair shares the plane and the diagonal a-c, so in the first triangle's own coordinates
+// (u = weight of b, v = weight of c) it covers 0 <= v <= 1, 0 <= u + v <= 1; the first triangle is
+// the part with u >= 0, the second the part with u <= 0.  One plane evaluation and two edge
+// functionals then serve two of upstream's triangle tests.  Within the error band of the diagonal
+// both triangles are reported (same lower bound), which sends the ray to the double-precision
+// tie-break.  Id word of such a row: kQuadFlag | second id << 13 | first id (ids < 8192: the
+// linear table is only used up to 4096 primitives).
+constexpr int32_t kQuadFlag = 1 << 30;
+constexpr int32_t kQuadIdBits = 13;
+
+struct RowEval { float u, v, w, bb, thi, tlo; bool dead; };
+
+RT_DEV RowEval row_eval(const TriRow &T, const Ray &r) {
+    RowEval e;
+    const float nd = fma_(T.nz, r.dz, fma_(T.ny, r.dy, T.nx * r.dx));
+    const float no = fma_(T.nz, r.oz, fma_(T.ny, r.oy, fma_(T.nx, r.ox, T.kn)));
+    const float inv = rcp_(nd);
+    const float t = -no * inv;
+    const float px = fma_(t, r.dx, r.ox), py = fma_(t, r.dy, r.oy), pz = fma_(t, r.dz, r.oz);
+    e.u = fma_(T.e1z, pz, fma_(T.e1y, py, fma_(T.e1x, px, T.k1)));
+    e.v = fma_(T.e2z, pz, fma_(T.e2y, py, fma_(T.e2x, px, T.k2)));
+    e.w = (1.0f - e.u) - e.v;
+    const float g = fma_(r.c7, abs_(t), r.c4) * abs_(inv);
+    e.bb = g * T.cb;
+    e.thi = fma_(g, T.ct, t);
+    e.tlo = fma_(-g, T.ct, t);
+    // det_lo = +inf marks the padding rows at the end of a table: never candidates (NaN included)
+    e.dead = !(abs_(nd) >= T.det_lo);
+    return e;
+}
+
+RT_DEV float row_tl(const RowEval &e, float m) {
+    const float x = min_(m + e.bb, e.thi);
+    const float y = x * (-kInf);                 // x < 0 -> +inf (not a candidate); x >= 0 -> -inf / NaN
+    return max_(max_(e.tlo, 0.0f), y);           // NaNs drop out of max: a NaN anywhere keeps the candidate
+}
+
+template <class Sink>
+RT_DEV void tri_row_candidates(const TriRow &T, const Ray &r, Sink &sink) {
+    const RowEval e = row_eval(T, r);
+    const float tl = row_tl(e, min_(min_(e.u, e.v), e.w));
+    sink((e.dead || T.gprim == r.origin) ? kInf : tl, T.gprim);
+}
+
+template <class Sink>
+RT_DEV void quad_row_candidates(const TriRow &T, const Ray &r, Sink &sink) {
+    const RowEval e = row_eval(T, r);
+    const int32_t id1 = T.gprim & ((1 << kQuadIdBits) - 1), id2 = (T.gprim >> kQuadIdBits) & ((1 << kQuadIdBits) - 1);
+    const float tl = row_tl(e, min_(min_(e.v, 1.0f - e.v), min_(e.u + e.v, e.w)));
+    const bool first = e.u >= 0.0f;
+    const int32_t idp = first ? id1 : id2, ido = first ? id2 : id1;
+    const bool clear = abs_(e.u) > e.bb;         // false for NaN: then both are reported
+    sink((e.dead || idp == r.origin) ? kInf : tl, idp);
+    sink((e.dead || clear || ido == r.origin) ? kInf : tl, ido);
+}
+
+// Brute-force loops over the two linear tables (parallelogram rows, then triangle rows), two rows
+// per trip.  Each table is padded with dead rows to an even count plus two, so the loops need no
+// tail and may read one trip ahead: a row's scalar load is issued a full test (~40 vector
+// instructions) before the row is used.
 template <class Sink>
 RT_DEV void search_tris(const DevScene &S, const Ray &r, Sink &sink) {
-    const int n = S.n_tri_rows_padded;   // even; rows [n, n+2) exist and are dead
-    if (n <= 0) return;
-    const TriRow *rows = S.tri_rows;
-    TriRow a0 = load_tri_row_uniform(rows, 0), a1 = load_tri_row_uniform(rows, 1);
-    for (int i = 0; i < n; i += 2) {
-        sink(tri_tlo<false>(a0, r, nullptr), a0.gprim);
-        a0 = load_tri_row_uniform(rows, i + 2);
-        sink(tri_tlo<false>(a1, r, nullptr), a1.gprim);
-        a1 = load_tri_row_uniform(rows, i + 3);
+    if (S.n_quad_rows_padded > 0) {
+        const int n = S.n_quad_rows_padded;
+        const TriRow *rows = S.quad_rows;
+        TriRow a0 = load_tri_row_uniform(rows, 0), a1 = load_tri_row_uniform(rows, 1);
+        for (int i = 0; i < n; i += 2) {
+            quad_row_candidates(a0, r, sink);
+            a0 = load_tri_row_uniform(rows, i + 2);
+            quad_row_candidates(a1, r, sink);
+            a1 = load_tri_row_uniform(rows, i + 3);
+        }
+    }
+    if (S.n_tri_rows_padded > 0) {
+        const int n = S.n_tri_rows_padded;   // even; rows [n, n+2) exist and are dead
+        const TriRow *rows = S.tri_rows;
+        TriRow a0 = load_tri_row_uniform(rows, 0), a1 = load_tri_row_uniform(rows, 1);
+        for (int i = 0; i < n; i += 2) {
+            tri_row_candidates(a0, r, sink);
+            a0 = load_tri_row_uniform(rows, i + 2);
+            tri_row_candidates(a1, r, sink);
+            a1 = load_tri_row_uniform(rows, i + 3);
+        }
     }
 }
 

@@ -70,8 +70,10 @@ struct ColdScene {
 
 struct DevScene {
     // float32 filter tables
-    const TriRow *tri_rows;   int32_t n_tri_rows;     // live triangles only, padded with dead rows:
+    const TriRow *tri_rows;   int32_t n_tri_rows;     // live triangles the table stands for (a parallelogram row counts two);
+                                                      // rows are padded with dead ones:
     int32_t n_tri_rows_padded;                        //   even, and 2 more rows exist past it
+    const TriRow *quad_rows;  int32_t n_quad_rows_padded;   // parallelogram rows (two triangles each), padded likewise
     const SphRow *sph_rows;   int32_t n_sph_rows;     // small spheres only
     const int32_t *big_sph;   int32_t n_big_sph;      // sphere indices evaluated in float64
     const TriRow *tri_by_id;                          // [n_tris] same rows, indexed by triangle id
