@@ -311,23 +311,21 @@ RT_DEV void search_tris(const DevScene &S, const Ray &r, Sink &sink) {
     if (S.n_quad_rows_padded > 0) {
         const int n = S.n_quad_rows_padded;
         const TriRow *rows = S.quad_rows;
-        TriRow a0 = load_tri_row_uniform(rows, 0), a1 = load_tri_row_uniform(rows, 1);
-        for (int i = 0; i < n; i += 2) {
-            quad_row_candidates(a0, r, sink);
-            a0 = load_tri_row_uniform(rows, i + 2);
-            quad_row_candidates(a1, r, sink);
-            a1 = load_tri_row_uniform(rows, i + 3);
+        TriRow cur = load_tri_row_uniform(rows, 0);
+        for (int i = 0; i < n; ++i) {
+            const TriRow next = load_tri_row_uniform(rows, i + 1);
+            quad_row_candidates(cur, r, sink);
+            cur = next;
         }
     }
     if (S.n_tri_rows_padded > 0) {
-        const int n = S.n_tri_rows_padded;   // even; rows [n, n+2) exist and are dead
+        const int n = S.n_tri_rows_padded;   // rows [n, n+2) exist and are dead
         const TriRow *rows = S.tri_rows;
-        TriRow a0 = load_tri_row_uniform(rows, 0), a1 = load_tri_row_uniform(rows, 1);
-        for (int i = 0; i < n; i += 2) {
-            tri_row_candidates(a0, r, sink);
-            a0 = load_tri_row_uniform(rows, i + 2);
-            tri_row_candidates(a1, r, sink);
-            a1 = load_tri_row_uniform(rows, i + 3);
+        TriRow cur = load_tri_row_uniform(rows, 0);
+        for (int i = 0; i < n; ++i) {
+            const TriRow next = load_tri_row_uniform(rows, i + 1);
+            tri_row_candidates(cur, r, sink);
+            cur = next;
         }
     }
 }
