@@ -354,21 +354,28 @@ RT_DEV TriRow load_tri_row_lane(const TriRow *rows, int i) {
 // beyond the sink's bound.
 struct BvhCounters { uint32_t nodes, tris; };
 
+//
+// The walk is resumable: it starts at `node` (0 = root), visits at most `budget` boxes before
+// returning, and leaves in `node` where to go on (-1 = finished).  The render kernel walks in
+// slices so that lanes whose rays finish early can take new work instead of idling until the
+// slowest ray of the wave (one that grazes a dense mesh visits ten times the average) is through.
 template <class Sink>
-RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters &bc) {
+RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters &bc, int &node, int budget) {
     const float ix = rcp_(r.dx), iy = rcp_(r.dy), iz = rcp_(r.dz);
     const float pad = 10.0f * kU * (r.o2 + S.scene_radius);
     const float oxp = r.ox + pad, oyp = r.oy + pad, ozp = r.oz + pad;   // subtracted from the low planes
     const float oxm = r.ox - pad, oym = r.oy - pad, ozm = r.oz - pad;   // subtracted from the high planes
     const f4 *nodes = (const f4 *)S.bvh_nodes;
     const TriRow *rows = S.tri_rows;
-    int node = S.n_bvh_nodes > 0 ? 0 : -1;
+    if (S.n_bvh_nodes <= 0) node = -1;
+    int visited = 0;
     // Two nested loops ("while-while"): every lane first walks boxes until it stands on a leaf, then
     // the lanes test their leaves' triangles together.  With a single loop the few lanes that are on
     // a leaf at any moment would make the whole wave run the triangle code on every trip.
-    for (;;) {
+    while (visited < budget) {
         int32_t leaf = -1;
-        while (node >= 0) {
+        while (node >= 0 && visited < budget) {
+            ++visited;
             const f4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
             const float skip_bits = a.w, leaf_bits = b.w;
             const int32_t skip = (int32_t)f2u(skip_bits), info = (int32_t)f2u(leaf_bits);
@@ -552,7 +559,7 @@ RT_DEV void search_all(const DevScene &S, const Ray &r, D3 o64, D3 d64, Sink &si
         search_big_spheres(S, r, o64, d64, sink);
     }
     if (TRI == kTriBrute) search_tris(S, r, sink);
-    if (TRI == kTriBvh) search_bvh(S, r, sink, bc);
+    if (TRI == kTriBvh) { int node = 0; search_bvh(S, r, sink, bc, node, 0x7FFFFFFF); }
 }
 
 RT_DEV void exact_scan_pass(const DevScene &S, D3 o64, D3 d64, int32_t origin, ExactHit &e, int32_t &gprim) {
@@ -563,36 +570,68 @@ RT_DEV void exact_scan_pass(const DevScene &S, D3 o64, D3 d64, int32_t origin, E
     if (!e.hit) gprim = -1;
 }
 
-// `e64`, when given, receives the double-precision record whenever the exact code produced the hit
-// (e64->hit says whether it did).
-template <int TRI, bool HAS_SPH, bool STRICT>
-RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, ExactHit *e64, const RayResidue rr) {
-    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
-    h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0;
-    // only the rare double-precision branches below read these; the loads and conversions sink into them
+struct Ray64 { D3 o, d; };
+
+// The ray the exact code sees: the float32 ray plus, for a pinhole camera ray, its residue.
+RT_DEV Ray64 ray64(const Ray &r, const RayResidue rr) {
+    // only rare double-precision branches read these; the loads and conversions sink into them
     float rdx = 0.0f, rdy = 0.0f, rdz = 0.0f, rox = 0.0f, roy = 0.0f, roz = 0.0f;
     if (rr.on) {
         const f4 q = *(const f4 *)(rr.table + 4 * (size_t)rr.pixel);
         rdx = q.x; rdy = q.y; rdz = q.z; rox = rr.ox; roy = rr.oy; roz = rr.oz;
     }
-    const D3 o64 = d3((double)r.ox + (double)rox, (double)r.oy + (double)roy, (double)r.oz + (double)roz);
-    const D3 d64 = d3((double)r.dx + (double)rdx, (double)r.dy + (double)rdy, (double)r.dz + (double)rdz);
-    ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
-    BvhCounters bc; bc.nodes = 0; bc.tris = 0;
-    bool scan = ray_needs_exact(r);
-    bool second = false; float limit = kInf; int32_t skip = -1;
-    int32_t gprim = -1; int root = 0; float t = kInf;
-    if (TRI == kTriBvh) {
-        // A ray with a zero direction component is within the hierarchy walk's reach (see search_bvh),
-        // and a double-precision scan of a million triangles by one lane would stall its whole wave
-        // for a long time, so it is settled by the second pass with every candidate open instead.
-        const bool len_ok = (r.a >= 0.25f) && (r.a <= 4.0f) && (r.o2 < 1e18f);
-        if (scan && len_ok) { scan = false; second = true; }
+    Ray64 x;
+    x.o = d3((double)r.ox + (double)rox, (double)r.oy + (double)roy, (double)r.oz + (double)roz);
+    x.d = d3((double)r.dx + (double)rdx, (double)r.dy + (double)rdy, (double)r.dz + (double)rdz);
+    return x;
+}
+
+// How a ray is answered: kRouteFilter = float32 first pass (the normal case); kRouteOpen = no first
+// pass, the second pass with every candidate open; kRouteScan = upstream's loops in double precision.
+enum { kRouteFilter = 0, kRouteOpen = 1, kRouteScan = 2 };
+
+template <int TRI>
+RT_DEV int ray_route(const Ray &r) {
+    if (!ray_needs_exact(r)) return kRouteFilter;
+    // With a hierarchy, a ray that only has a zero direction component is within the walk's reach
+    // (see search_bvh), and a double-precision scan of a million triangles by one lane would stall
+    // its whole wave for a long time: the second pass settles it instead.
+    const bool len_ok = (r.a >= 0.25f) && (r.a <= 4.0f) && (r.o2 < 1e18f);
+    return (TRI == kTriBvh && len_ok) ? kRouteOpen : kRouteScan;
+}
+
+template <int TRI> struct FirstPass { typedef typename std::conditional<TRI == kTriBvh, PairBest, KeyBest>::type type; };
+
+// First pass without the hierarchy walk: spheres and the linear tables.
+template <int TRI, bool HAS_SPH>
+RT_DEV void hit_begin(const DevScene &S, const Ray &r, const RayResidue rr, typename FirstPass<TRI>::type &first) {
+    first.init(S);
+    if (HAS_SPH) {
+        search_spheres(S, r, first);
+        if (S.n_big_sph > 0) {
+            const Ray64 x = ray64(r, rr);
+            search_big_spheres(S, r, x.o, x.d, first);
+        }
     }
-    if (!scan && !second) {
-        typename std::conditional<TRI == kTriBvh, PairBest, KeyBest>::type first;
-        first.init(S);
-        search_all<TRI, HAS_SPH>(S, r, o64, d64, first, bc);
+    if (TRI == kTriBrute) search_tris(S, r, first);
+}
+
+// Everything after the first pass: judge the winner, settle contenders, build the hit record.
+// `e64`, when given, receives the double-precision record whenever the exact code produced the hit
+// (e64->hit says whether it did).
+template <int TRI, bool HAS_SPH, bool STRICT>
+RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
+                      BvhCounters bc, ExactHit *e64) {
+    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
+    h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0;
+    const Ray64 x64 = ray64(r, rr);
+    const D3 o64 = x64.o, d64 = x64.d;
+    ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
+    const int route = ray_route<TRI>(r);
+    const bool scan = route == kRouteScan;
+    bool second = route == kRouteOpen; float limit = kInf; int32_t skip = -1;
+    int32_t gprim = -1; int root = 0; float t = kInf;
+    if (route == kRouteFilter) {
         if (first.any()) {
             gprim = first.best_id();
             const float second_lo = first.second_lo();
@@ -671,6 +710,19 @@ RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, ExactHit *e64, const Ray
         h.nx = A.nx; h.ny = A.ny; h.nz = A.nz;
     }
     return h;
+}
+
+// One closest-hit query from start to end.
+template <int TRI, bool HAS_SPH, bool STRICT>
+RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, ExactHit *e64, const RayResidue rr) {
+    typename FirstPass<TRI>::type first;
+    first.init(S);
+    BvhCounters bc; bc.nodes = 0; bc.tris = 0;
+    if (ray_route<TRI>(r) == kRouteFilter) {
+        hit_begin<TRI, HAS_SPH>(S, r, rr, first);
+        if (TRI == kTriBvh) { int node = 0; search_bvh(S, r, first, bc, node, 0x7FFFFFFF); }
+    }
+    return hit_finish<TRI, HAS_SPH, STRICT>(S, r, rr, first, bc, e64);
 }
 
 }  // namespace rt

@@ -225,16 +225,17 @@ RT_DEV void path_begin(const DevScene &S, const float *ray_dir, const float *ray
 }
 
 
-// One segment: closest hit, then environment or one bounce.  Returns true while the path goes on;
-// when it returns false (er, eg, eb) is the terminal radiance to be multiplied by (tr, tg, tb).
-template <int TRI, bool HAS_SPH>
-RT_DEV bool path_step(const DevScene &S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h) {
-    Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0);
+RT_DEV RayResidue path_residue(const DevScene &S, const float *ray_res, const Path &p) {
     // a pinhole camera ray is the rounding of a double-precision ray whose residue is in the table
     RayResidue rr;
     rr.table = ray_res; rr.pixel = p.pixel; rr.on = (p.depth == 0) && !S.dof_on;
     rr.ox = S.cam_res[0]; rr.oy = S.cam_res[1]; rr.oz = S.cam_res[2];
-    h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, rr);
+    return rr;
+}
+
+// What follows a closest-hit answer: environment or one bounce.  Returns true while the path goes
+// on; when it returns false (er, eg, eb) is the terminal radiance to be multiplied by (tr, tg, tb).
+RT_DEV bool path_shade(const DevScene &S, Path &p, int max_bounces, const Hit &h, float &er, float &eg, float &eb) {
     er = eg = eb = 0.0f;
     if (h.obj < 0) {
         environment(S, p.dx, p.dy, p.dz, er, eg, eb);
@@ -249,6 +250,14 @@ RT_DEV bool path_step(const DevScene &S, const float *ray_res, Path &p, int max_
     return alive;
 }
 
+// One segment: closest hit, then environment or one bounce.
+template <int TRI, bool HAS_SPH>
+RT_DEV bool path_step(const DevScene &S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h) {
+    Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0);
+    h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, path_residue(S, ray_res, p));
+    return path_shade(S, p, max_bounces, h, er, eg, eb);
+}
+
 RT_DEV uint32_t fast_div(uint32_t n, const FastDiv &f) {
     const uint32_t t = __umulhi(f.m, n);
     return (t + ((n - t) >> f.sh1)) >> f.sh2;
@@ -260,6 +269,7 @@ RT_DEV uint32_t rank_in(unsigned long long mask) {
 }
 
 constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at a time
+constexpr int kWalkSlice = 24;   // boxes a lane visits per trip of the render loop (hierarchy scenes)
 
 template <int TRI, bool HAS_SPH>
 __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const RenderArgs A) {
@@ -277,7 +287,12 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
     // Statistics are kept per WAVE in scalar registers (lane counts of ballots taken where the wave
     // is converged), not per lane: six vector registers less for the whole life of the kernel.
     uint32_t w_rays = 0, w_paths = 0, w_exact = 0, w_refine = 0, w_sky = 0, w_shaded = 0;
-    uint32_t l_nodes = 0, l_tris = 0;   // hierarchy only: per-lane sums, reduced at the end
+    BvhCounters bc; bc.nodes = 0; bc.tris = 0;   // hierarchy only: per-lane sums, reduced at the end
+    // hierarchy only: a closest-hit query in progress (walked a slice per trip of the main loop)
+    typename FirstPass<TRI>::type first;
+    first.init(S);
+    int walk_node = -1;
+    bool walking = false;
     const uint32_t rect_px = (uint32_t)(A.rect_w * A.rect_h);
 
     for (;;) {
@@ -315,8 +330,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
 
         const bool starting = have_job && !in_path;
         w_paths += (uint32_t)__builtin_popcountll(__ballot(starting));
-        w_rays += (uint32_t)__builtin_popcountll(__ballot(have_job));
-        bool f_exact = false, f_refine = false, f_sky = false, f_shaded = false;
+        bool f_ray = false, f_exact = false, f_refine = false, f_sky = false, f_shaded = false;
         if (have_job) {
             // ---- 2. start the next sample of this lane's pixel --------------------------------
             if (!in_path) {
@@ -324,11 +338,33 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
                 in_path = true;
             }
             // ---- 3. one path segment ----------------------------------------------------------
-            float er, eg, eb;
+            float er = 0.0f, eg = 0.0f, eb = 0.0f;
             Hit h;
-            bool alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h);
-            f_exact = h.how == 2; f_refine = h.refined; f_sky = h.obj < 0; f_shaded = h.obj >= 0;
-            if (TRI == kTriBvh) { l_nodes += h.bvh_nodes; l_tris += h.bvh_tris; }
+            bool alive = true;
+            if (TRI == kTriBvh) {
+                // resumable query: begin it if none is open, walk one slice, finish it when the walk is through
+                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0);
+                const RayResidue rr = path_residue(S, A.ray_res, p);
+                if (!walking) {
+                    walking = true;
+                    walk_node = -1;
+                    first.init(S);
+                    if (ray_route<TRI>(ray) == kRouteFilter) { hit_begin<TRI, HAS_SPH>(S, ray, rr, first); walk_node = 0; }
+                }
+                if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, kWalkSlice);
+                if (walk_node < 0) {
+                    walking = false;
+                    BvhCounters second_pass; second_pass.nodes = 0; second_pass.tris = 0;
+                    h = hit_finish<TRI, HAS_SPH, false>(S, ray, rr, first, second_pass, nullptr);
+                    bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
+                    alive = path_shade(S, p, A.max_bounces, h, er, eg, eb);
+                    f_ray = true;
+                }
+            } else {
+                alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h);
+                f_ray = true;
+            }
+            if (f_ray) { f_exact = h.how == 2; f_refine = h.refined; f_sky = h.obj < 0; f_shaded = h.obj >= 0; }
             if (!alive) {
                 ar = fma_(p.tr, er, ar); ag = fma_(p.tg, eg, ag); ab = fma_(p.tb, eb, ab);
                 in_path = false;
@@ -345,13 +381,14 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
                 }
             }
         }
+        w_rays += (uint32_t)__builtin_popcountll(__ballot(f_ray));
         w_exact += (uint32_t)__builtin_popcountll(__ballot(f_exact));
         w_refine += (uint32_t)__builtin_popcountll(__ballot(f_refine));
         w_sky += (uint32_t)__builtin_popcountll(__ballot(f_sky));
         w_shaded += (uint32_t)__builtin_popcountll(__ballot(f_shaded));
     }
     // ---- statistics: one atomic per counter per wave ------------------------------------------
-    unsigned long long nodes = l_nodes, tris = l_tris;
+    unsigned long long nodes = bc.nodes, tris = bc.tris;
     if (TRI == kTriBvh) {
         for (int off = 32; off > 0; off >>= 1) { nodes += __shfl_down(nodes, off, 64); tris += __shfl_down(tris, off, 64); }
     }
