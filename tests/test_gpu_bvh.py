@@ -178,3 +178,36 @@ def test_bad_hierarchy_is_rejected(backend):
     with pytest.raises(BackendError, match="hierarchy"):
         backend.set_scene(dataclasses.replace(sc, bvh_nodes=nodes, bvh_tri_index=dup))
     backend.set_scene(dataclasses.replace(sc, bvh_nodes=nodes, bvh_tri_index=order))   # the good one is accepted
+
+
+def test_progressive_batches_and_device_tonemap(backend):
+    """Shape of BASELINE config 5 at test size: room + large mesh rendered progressively (sample
+    batches added into one device buffer, which is a torch tensor), then tone-mapped on the device
+    with upstream's main.py chain (exposure 2, brightness 0.02, contrast 1.1).  Batches must add up
+    to the one-shot render (same global sample indices -> same paths; float32 summation order is
+    the only difference), and the device tone-map must equal the numpy one on the read-back."""
+    import torch
+
+    from raytracing_amd.post_processing import PostProcessing
+
+    base = h.packed_scene("room_horse")
+    backend.set_scene(base.with_subdivided_mesh(base.n_meshes - 1, 4))
+    W, H, spp, b = 160, 90, 12, 6
+    one = torch.zeros((W, H, 3), dtype=torch.float32, device="cuda:0")
+    backend.render(W, H, 0, spp, b, 77, accum_ptr=one.data_ptr())
+    backend.synchronize()
+    prog = torch.zeros_like(one)
+    previews = []
+    for s0 in range(0, spp, 4):
+        backend.render(W, H, s0, 4, b, 77, accum_ptr=prog.data_ptr())
+        backend.synchronize()
+        previews.append((prog / float(s0 + 4)).flip(1))     # RenderResult.img_arr of the passes so far
+    torch.cuda.synchronize()
+    a, p = one.cpu().numpy(), prog.cpu().numpy()
+    assert np.allclose(a, p, rtol=2e-6, atol=1e-6), np.abs(a - p).max()
+    pp = PostProcessing(exposure=2, brightness=0.02, contrast=1.1)
+    dev = pp.process(previews[-1])
+    assert dev.is_cuda
+    host = pp.process(previews[-1].cpu().numpy().astype(np.float64))
+    assert np.abs(dev.cpu().numpy() - host).max() < 2e-5
+    assert float(previews[0].mean()) > 0 and len(previews) == 3
