@@ -61,7 +61,7 @@ struct rt_ctx {
     bool has_scene = false;
     DevScene S{};
     int tri_mode = 0; bool has_sph = false;
-    DevBuf tri_rows, quad_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
+    DevBuf tri_rows, quad_rows, leaf_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
@@ -187,6 +187,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     if (!use_bvh && n_gprim > 4096)
         return fail(c, RT_ERR_UNSUPPORTED, "%lld primitives without triangles: the linear sphere walk takes at most 4096", n_gprim);
     std::vector<rt_bvh_node> bvh_nodes; std::vector<int32_t> bvh_order;
+    std::vector<char> linear_tri;   // with a hierarchy: triangles that stay in the linear table instead (empty = none)
     if (use_bvh) {
         if (d->n_bvh_nodes > 0) {
             if (!d->bvh_nodes || !d->bvh_tri_index) return fail(c, RT_ERR_INVALID_ARG, "n_bvh_nodes > 0 with a NULL table");
@@ -196,8 +197,41 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             bvh_nodes.assign(nn, nn + d->n_bvh_nodes);
             bvh_order.assign(d->bvh_tri_index, d->bvh_tri_index + d->n_tris);
         } else {
+            // Triangles that span a sizeable part of the scene (walls, floors) would sit in leaves near
+            // the root whose boxes nearly every ray enters, and each test there costs four divergent
+            // 16-byte loads per lane; the linear table tests them from scalar registers instead.  Up
+            // to 128 triangles whose box area is at least 1 % of the scene's stay out of the hierarchy.
+            std::vector<double> area(d->n_tris, 0.0);
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int t = 0; t < d->n_tris; ++t) {
+                const double *v = d->tri_verts + 9 * (size_t)t;
+                double e[3];
+                bool finite = true;
+                for (int k = 0; k < 9; ++k) finite = finite && std::isfinite(v[k]);
+                if (!finite) continue;
+                for (int k = 0; k < 3; ++k) {
+                    const double l = std::min({v[k], v[3 + k], v[6 + k]}), h = std::max({v[k], v[3 + k], v[6 + k]});
+                    e[k] = h - l; lo[k] = std::min(lo[k], l); hi[k] = std::max(hi[k], h);
+                }
+                area[t] = e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+            }
+            const double scene_area = (hi[0] - lo[0]) * (hi[1] - lo[1]) + (hi[1] - lo[1]) * (hi[2] - lo[2]) + (hi[2] - lo[2]) * (hi[0] - lo[0]);
+            std::vector<int32_t> large;
+            if (std::getenv("RAYTRACING_AMD_NO_LINEAR_SPLIT") == nullptr)
+                for (int t = 0; t < d->n_tris; ++t) if (area[t] >= 0.01 * scene_area) large.push_back(t);
+            if (large.size() > 128) {
+                std::sort(large.begin(), large.end(), [&](int32_t a, int32_t b) { return area[a] > area[b]; });
+                large.resize(128);
+            }
+            linear_tri.assign(d->n_tris, 0);
+            for (int32_t t : large) linear_tri[t] = 1;
+            std::vector<int32_t> rest;
+            rest.reserve(d->n_tris - large.size());
+            for (int t = 0; t < d->n_tris; ++t) if (!linear_tri[t]) rest.push_back(t);
+            if (rest.empty()) { rest.push_back(large.back()); linear_tri[large.back()] = 0; }   // keep the hierarchy non-empty
             bvh::Builder b;
-            b.run(d->n_tris, d->tri_verts, 4);
+            const char *leaf_env = std::getenv("RAYTRACING_AMD_BVH_LEAF");   // tuning switch; default 4
+            b.run(d->n_tris, d->tri_verts, leaf_env ? std::atoi(leaf_env) : 4, &rest);
             bvh_nodes.swap(b.nodes); bvh_order.swap(b.order);
         }
     }
@@ -296,17 +330,18 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     std::vector<TriRow> rows_live, rows_quad;
     int n_live_tris = 0;
     {
-        const bool merge_pairs = !use_bvh && std::getenv("RAYTRACING_AMD_NO_QUADS") == nullptr;   // switch for A/B runs and tests
+        const bool merge_pairs = std::getenv("RAYTRACING_AMD_NO_QUADS") == nullptr;   // switch for A/B runs and tests
+        auto in_linear = [&](int t) { return !use_bvh || (!linear_tri.empty() && linear_tri[t]); };
         std::vector<char> taken(d->n_tris, 0);
         auto vtx = [&](int t, int k) { const double *v = d->tri_verts + 9 * (size_t)t + 3 * k; return V3{v[0], v[1], v[2]}; };
         auto same = [](V3 p, V3 q) { return p.x == q.x && p.y == q.y && p.z == q.z; };
         for (int t = 0; t < d->n_tris; ++t) {
-            if (taken[t] || !(rows_all[t].det_lo < INFINITY)) continue;
+            if (taken[t] || !in_linear(t) || !(rows_all[t].det_lo < INFINITY)) continue;
             TriRow r = rows_all[t];
             ++n_live_tris;
             const int mesh_end = d->mesh_tri_begin[tri_mesh[t] + 1];
-            for (int y = t + 1; merge_pairs && y < std::min(mesh_end, t + 65) && n_gprim < (1 << kQuadIdBits); ++y) {
-                if (taken[y] || !(rows_all[y].det_lo < INFINITY)) continue;
+            for (int y = t + 1; merge_pairs && y < std::min(mesh_end, t + 65) && d->n_spheres + y < (1 << kQuadIdBits); ++y) {
+                if (taken[y] || !in_linear(y) || !(rows_all[y].det_lo < INFINITY)) continue;
                 // shared vertices (bitwise equal), and each triangle's remaining one
                 int xs = -1, ys = -1, n_shared = 0;
                 bool x_shared[3] = {false, false, false}, y_shared[3] = {false, false, false};
@@ -364,10 +399,10 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     std::vector<int32_t> sobj(d->sphere_obj, d->sphere_obj + d->n_spheres);
     // pad the live rows with dead ones (det_lo = +inf) to an even count, plus two to read ahead
     int n_live = n_live_tris;
+    std::vector<TriRow> rows_leaf;
     if (use_bvh) {   // the walk reads rows in leaf order (dead triangles included: they kill themselves)
-        rows_live.resize(d->n_tris);
-        for (int k = 0; k < d->n_tris; ++k) rows_live[k] = rows_all[bvh_order[k]];
-        n_live = d->n_tris;
+        rows_leaf.resize(bvh_order.size());
+        for (size_t k = 0; k < bvh_order.size(); ++k) rows_leaf[k] = rows_all[bvh_order[k]];
     }
     const bool any_tri_rows = !rows_live.empty(), any_quad_rows = !rows_quad.empty();
     for (auto *tab : {&rows_live, &rows_quad}) {
@@ -376,13 +411,22 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         while (tab->size() % 2) tab->push_back(dead);
         for (int k = 0; k < 2; ++k) tab->push_back(dead);
     }
-    HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
+    HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->leaf_rows.upload(rows_leaf)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
     HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
     HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));
     HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
     HIP_TRY(c, c->mesh_tri_begin.upload(mtb)); HIP_TRY(c, c->obj_kind.upload(okind)); HIP_TRY(c, c->obj_index.upload(oindex));
     if (has_sky) HIP_TRY(c, c->sky.upload(sky));
-    if (use_bvh) HIP_TRY(c, c->bvh.upload(bvh_nodes));
+    if (use_bvh) {
+        // eight threadings of the one hierarchy, one per octant of ray directions (front-to-back order)
+        std::vector<rt_bvh_node> all, one;
+        all.reserve(8 * bvh_nodes.size());
+        for (int oct = 0; oct < 8; ++oct) {
+            bvh::rethread(bvh_nodes, oct, one);
+            all.insert(all.end(), one.begin(), one.end());
+        }
+        HIP_TRY(c, c->bvh.upload(all));
+    }
 
     DevScene &S = c->S;
     S = DevScene{};
@@ -393,6 +437,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();
     S.sph_by_id = c->sph_by_id.as<SphRow>(); S.sph_obj = c->sph_obj.as<int32_t>();
     S.materials = c->materials.as<MatRow>();
+    S.leaf_rows = c->leaf_rows.as<TriRow>();
     S.bvh_nodes = use_bvh ? c->bvh.as<BvhNode>() : nullptr; S.n_bvh_nodes = use_bvh ? (int32_t)bvh_nodes.size() : 0;
     ColdScene cold{};
     cold.tri64 = c->tri64.as<double>(); cold.sph64 = c->sph64.as<double>(); cold.aabb64 = c->aabb64.as<double>();

@@ -47,9 +47,12 @@ struct Builder {
     std::vector<int32_t> order;               // triangle ids, permuted in place; final leaf order
     std::vector<rt_bvh_node> nodes;
 
-    void run(int64_t n, const double *verts, int leaf_size) {
+    // `subset` (optional): the triangle ids to build over; the others appear in no leaf.
+    void run(int64_t n, const double *verts, int leaf_size, const std::vector<int32_t> *subset = nullptr) {
         leaf_target = std::max(1, std::min(leaf_size, kMaxLeaf));
-        tri_box.resize(n); centroid.resize(3 * (size_t)n); order.resize(n);
+        tri_box.resize(n); centroid.resize(3 * (size_t)n);
+        if (subset) order = *subset;
+        else { order.resize(n); for (int64_t t = 0; t < n; ++t) order[t] = (int32_t)t; }
         for (int64_t t = 0; t < n; ++t) {
             const double *v = verts + 9 * (size_t)t;
             Box b; b.reset();
@@ -59,11 +62,11 @@ struct Builder {
                 b.lo[k] = round_down(lo); b.hi[k] = round_up(hi);
                 centroid[3 * (size_t)t + k] = (float)(0.5 * (lo + hi));
             }
-            tri_box[t] = b; order[t] = (int32_t)t;
+            tri_box[t] = b;
         }
         nodes.clear();
         nodes.reserve((size_t)(2 * n / std::max(1, leaf_target)) + 16);
-        if (n > 0) build(0, (int32_t)n, 0);
+        if (!order.empty()) build(0, (int32_t)order.size(), 0);
         const int32_t total = (int32_t)nodes.size();
         for (auto &nd : nodes) if (nd.skip >= total) nd.skip = -1;
     }
@@ -152,6 +155,39 @@ struct Builder {
         nodes[idx].skip = (int32_t)nodes.size();
     }
 };
+
+// The same hierarchy threaded for one octant of ray directions (bit k of `octant` set = direction
+// negative along axis k): at every inner node the child whose box centre comes first along the ray
+// is visited first, so a walk meets near geometry before far geometry and its depth bound prunes
+// the rest.  Subtree sizes do not depend on the order, so skip links follow from the source's.
+// `src` must have passed validate() (or come from Builder).
+inline void rethread(const std::vector<rt_bvh_node> &src, int octant, std::vector<rt_bvh_node> &dst) {
+    const int32_t n = (int32_t)src.size();
+    dst.clear(); dst.reserve(n);
+    auto end_of = [&](int32_t i) { return src[i].skip < 0 ? n : src[i].skip; };
+    std::vector<int32_t> stack;
+    if (n > 0) stack.push_back(0);
+    while (!stack.empty()) {
+        const int32_t i = stack.back(); stack.pop_back();
+        const int32_t idx = (int32_t)dst.size();
+        rt_bvh_node nd = src[i];
+        nd.skip = idx + (end_of(i) - i);
+        dst.push_back(nd);
+        if (src[i].tri_begin_count >= 0) continue;
+        const int32_t l = i + 1, r = end_of(l);
+        int axis = 0; float best = -1.0f, diff[3];
+        for (int k = 0; k < 3; ++k) {
+            diff[k] = (src[r].lo[k] + src[r].hi[k]) - (src[l].lo[k] + src[l].hi[k]);   // > 0: r lies further along +k
+            if (std::fabs(diff[k]) > best) { best = std::fabs(diff[k]); axis = k; }
+        }
+        const bool negative = (octant >> axis) & 1;
+        const bool l_first = negative ? !(diff[axis] > 0) : !(diff[axis] < 0);
+        const int32_t first = l_first ? l : r, second = l_first ? r : l;
+        stack.push_back(second);
+        stack.push_back(first);
+    }
+    for (auto &nd : dst) if (nd.skip >= n) nd.skip = -1;
+}
 
 // Structural and containment checks.  Returns an empty string when the hierarchy is safe to use:
 // links only point forward and nest, leaves index [0, n_tris) and cover every triangle exactly once,

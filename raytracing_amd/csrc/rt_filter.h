@@ -365,8 +365,10 @@ RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters 
     const float pad = 10.0f * kU * (r.o2 + S.scene_radius);
     const float oxp = r.ox + pad, oyp = r.oy + pad, ozp = r.oz + pad;   // subtracted from the low planes
     const float oxm = r.ox - pad, oym = r.oy - pad, ozm = r.oz - pad;   // subtracted from the high planes
-    const f4 *nodes = (const f4 *)S.bvh_nodes;
-    const TriRow *rows = S.tri_rows;
+    // the threading for this ray's octant: children nearer along the ray come first
+    const int oct = (r.dx < 0.0f ? 1 : 0) | (r.dy < 0.0f ? 2 : 0) | (r.dz < 0.0f ? 4 : 0);
+    const f4 *nodes = (const f4 *)(S.bvh_nodes + (size_t)oct * (size_t)S.n_bvh_nodes);
+    const TriRow *rows = S.leaf_rows;
     if (S.n_bvh_nodes <= 0) node = -1;
     int visited = 0;
     // Two nested loops ("while-while"): every lane first walks boxes until it stands on a leaf, then
@@ -558,7 +560,7 @@ RT_DEV void search_all(const DevScene &S, const Ray &r, D3 o64, D3 d64, Sink &si
         search_spheres(S, r, sink);
         search_big_spheres(S, r, o64, d64, sink);
     }
-    if (TRI == kTriBrute) search_tris(S, r, sink);
+    if (TRI != kTriNone) search_tris(S, r, sink);
     if (TRI == kTriBvh) { int node = 0; search_bvh(S, r, sink, bc, node, 0x7FFFFFFF); }
 }
 
@@ -613,7 +615,7 @@ RT_DEV void hit_begin(const DevScene &S, const Ray &r, const RayResidue rr, type
             search_big_spheres(S, r, x.o, x.d, first);
         }
     }
-    if (TRI == kTriBrute) search_tris(S, r, first);
+    if (TRI != kTriNone) search_tris(S, r, first);   // with a hierarchy: the few scene-sized triangles kept out of it
 }
 
 // Everything after the first pass: judge the winner, settle contenders, build the hit record.

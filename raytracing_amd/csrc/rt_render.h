@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const Rende
         v[kStatRays] = w_rays; v[kStatPaths] = w_paths; v[kStatExact] = w_exact; v[kStatRefine] = w_refine;
         v[kStatSky] = w_sky; v[kStatShaded] = w_shaded;
         v[kStatSphTests] = (unsigned long long)w_rays * (uint32_t)(S.n_sph_rows + S.n_big_sph);
-        v[kStatTriTests] = TRI == kTriBvh ? tris : (unsigned long long)w_rays * (uint32_t)S.n_tri_rows;   // dead padding rows are not counted
+        // linear-table tests (dead padding rows are not counted) plus, with a hierarchy, the leaf tests
+        v[kStatTriTests] = (unsigned long long)w_rays * (uint32_t)S.n_tri_rows + (TRI == kTriBvh ? tris : 0ull);
         v[kStatBvhNodes] = nodes;
 #pragma unroll
         for (int i = 0; i < kStatCount; ++i)

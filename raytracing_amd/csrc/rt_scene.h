@@ -82,7 +82,9 @@ struct DevScene {
     const int32_t *sph_obj;                           // [n_spheres]
     const MatRow *materials;                          // [n_objects]
     const ColdScene *cold;                            // device memory
-    const BvhNode *bvh_nodes; int32_t n_bvh_nodes;    // threaded hierarchy over tri_rows (then in leaf order); 0 = none
+    const TriRow *leaf_rows;                          // hierarchy: triangle rows in leaf order
+    const BvhNode *bvh_nodes; int32_t n_bvh_nodes;    // threaded hierarchy over tri_rows (then in leaf order), 8 copies of
+                                                      // n_bvh_nodes nodes, one per ray-direction octant; 0 = none
     int32_t n_spheres;
     float scene_radius;       // bound on the distance from the world origin of every vertex, small-sphere point and the camera
     uint32_t key_mask;        // low bits of a hit key that hold the primitive id
