@@ -272,7 +272,7 @@ constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at
 constexpr int kWalkSlice = 12;   // boxes a lane visits per trip of the render loop (hierarchy scenes)
 
 template <int TRI, bool HAS_SPH>
-__global__ __launch_bounds__(256, 4) void k_render(const DevScene S, const RenderArgs A) {
+__global__ __launch_bounds__(256, TRI == kTriBvh ? 3 : 4) void k_render(const DevScene S, const RenderArgs A) {
     // wave-uniform job window
     uint32_t win_next = 0, win_end = 0;
     bool drained = false;
