@@ -46,6 +46,16 @@ def load_room():
     return PackedScene.load(os.path.join(gold, "scene_room.npz"), sky_rgb=sky)
 
 
+def measured_traffic():
+    """HBM bytes per launch of the render kernel on THIS workload, from the committed PMC passes
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside a timed benchmark); None if absent."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r1_hbm_traffic.json")) as fh:
+            return float(json.load(fh)["bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def algorithmic_flops(st: dict) -> float:
     return (st["sphere_tests"] * F_SPHERE + st["tri_tests"] * F_TRI + st["shaded_hits"] * F_SHADE
             + st["paths"] * F_RAYGEN + st["sky_lookups"] * F_SKY)
@@ -163,7 +173,9 @@ def main() -> None:
             "samples_per_s": paths_all / dt_all,
             "rays_per_path": rays_all / max(paths_all, 1.0),
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": measured_traffic() if world == 1 else None,
+                         "traffic_note": "HBM bytes per launch at N=1, PMC passes in profiles/r1_hbm_traffic.json (2*FETCH_SIZE + WRITE_SIZE)",
                          "kernel": "rt::k_render", "kernel_ms_per_launch": kernel_s * 1e3,
                          "flops_per_launch": flops_launch,
                          "exact_ray_fraction": st["exact_rays"] / max(st["rays"], 1),
