@@ -104,9 +104,17 @@ def main() -> None:
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # One rank per GPU.  RT_BENCH_BACKEND=gloo (a rehearsal switch) lets several ranks share the
+    # GPUs that exist, e.g. two ranks on a one-GPU box, to exercise the sharded path without RCCL.
+    backend_name = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if backend_name != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend_name)
 
     from raytracing_amd.backend.lib import HipBackend
     from raytracing_amd.distributed import DistributedRenderer
@@ -128,15 +136,24 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace = os.environ.get("RT_BENCH_TRACE")   # progress lines on stderr, for locating a stall
+
+    def say(msg):
+        if trace:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    say("scene set, warming up")
     for _ in range(a.warmup):
         step()
     fence()
+    say("warm-up done")
     be.reset_stats()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    say("timed steps done")
     st = be.stats()   # this rank's counters over the timed steps
 
     # whole-job numbers: sum of rays over ranks, max of time over ranks
@@ -148,6 +165,7 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     rays_all, paths_all, flops_all, kms_all = [float(x) for x in tot.tolist()]
     dt_all = float(tmax.item())
+    say("reduced")
 
     if rank == 0:
         launches = max(int(st["launches"]), 1)
@@ -181,7 +199,7 @@ def main() -> None:
                          "exact_ray_fraction": st["exact_rays"] / max(st["rays"], 1),
                          "refined_hit_fraction": st["refined_hits"] / max(st["rays"], 1)},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -66,7 +66,8 @@ struct rt_ctx {
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
     DevBuf ray_dir, ray_res; int ray_w = 0, ray_h = 0;   // camera-ray table of the current scene at ray_w x ray_h
-    std::vector<EventPair> timed;
+    std::vector<EventPair> timed;        // recorded around render launches, not yet read
+    std::vector<EventPair> spare_events; // read and ready for reuse (events are created once, not per launch)
     double kernel_ms = 0; uint64_t launches = 0;
 };
 
@@ -142,7 +143,8 @@ int rt_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (auto &e : ctx->timed) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto *v : {&ctx->timed, &ctx->spare_events})
+        for (auto &e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete ctx;
     return RT_OK;
 }
@@ -680,7 +682,9 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     const long long waves_needed = (total_jobs + 63) / 64;
     const unsigned blocks = (unsigned)std::min<long long>((waves_needed + 3) / 4, (long long)c->n_cu * 8);
     EventPair ev;
-    HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b));
+    bool have_ev = false;
+    { std::lock_guard<std::mutex> g(c->mu); if (!c->spare_events.empty()) { ev = c->spare_events.back(); c->spare_events.pop_back(); have_ev = true; } }
+    if (!have_ev) { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
     HIP_TRY(c, hipEventRecord(ev.a, stream));
     const DevScene S = c->S;
     dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
@@ -713,9 +717,8 @@ static int drain_events(rt_ctx *c) {
     for (auto &e : evs) {
         float ms = 0;
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) ms_sum += ms;
-        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
-    { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms += ms_sum; }
+    { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms += ms_sum; c->spare_events.insert(c->spare_events.end(), evs.begin(), evs.end()); }
     return RT_OK;
 }
 

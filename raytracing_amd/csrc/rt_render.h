@@ -269,7 +269,7 @@ RT_DEV uint32_t rank_in(unsigned long long mask) {
 }
 
 constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at a time
-constexpr int kWalkSlice = 12;   // boxes a lane visits per trip of the render loop (hierarchy scenes)
+constexpr int kWalkSlice = 8;   // boxes a lane visits per trip of the render loop (hierarchy scenes)
 
 template <int TRI, bool HAS_SPH>
 __global__ __launch_bounds__(256, TRI == kTriBvh ? 3 : 4) void k_render(const DevScene S, const RenderArgs A) {
