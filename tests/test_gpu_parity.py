@@ -303,3 +303,66 @@ def test_renderer_api_end_to_end(backend):
     assert np.allclose(on_dev, on_host, atol=2e-5)
     hits = scene.intersect(raytracing.Camera.get_ray(scene.camera, 0.0, 0.0))
     assert len(hits) == 1 and hits[0].obj is scene.objects[0]
+
+
+def test_parallelogram_rows_equal_triangle_rows(backend, monkeypatch):
+    """Two triangles that share a diagonal are tested as one table row; the answers must be those of
+    the per-triangle rows (switch RAYTRACING_AMD_NO_QUADS) and of the oracle - in particular ON the
+    diagonal, where both triangles are hit at the same depth and upstream's stable sort keeps the
+    first face (scene.py:24-27).  Scene: the room (axis-aligned rectangles, and two walls whose
+    corners are parallelograms only up to decimal-to-binary rounding) plus a tilted rectangle and
+    a non-parallelogram quad that must NOT be merged."""
+    import dataclasses
+
+    base = h.packed_scene("room")
+    rng = np.random.default_rng(42)
+    # tilted rectangle a, b, c, d (exact parallelogram in binary) split along a-c, then along b-d order
+    a, b, d = np.array([-0.5, -0.25, 0.125]), np.array([0.25, -0.5, 0.375]), np.array([-0.375, 0.5, -0.25])
+    c = b + d - a
+    kite = [np.array([0.6, -0.9, -0.4]), np.array([0.9, -0.9, -0.4]), np.array([0.95, -0.55, -0.35]), np.array([0.6, -0.6, -0.4])]
+    extra = np.array([np.concatenate([a, b, c]), np.concatenate([a, c, d]),
+                      np.concatenate([kite[0], kite[1], kite[2]]), np.concatenate([kite[0], kite[2], kite[3]])])
+    lamp = base.n_meshes - 1
+    tv = np.concatenate([base.tri_verts, extra])
+    begin = base.mesh_tri_begin.copy()
+    begin[-1] += 4                                   # the four new faces join the last mesh
+    aabb = base.mesh_aabb.copy()
+    pts = tv[begin[lamp]:begin[lamp + 1]].reshape(-1, 3)
+    aabb[lamp] = np.concatenate([pts.min(0), pts.max(0)])
+    sc = dataclasses.replace(base, tri_verts=np.ascontiguousarray(tv), mesh_tri_begin=begin, mesh_aabb=aabb)
+
+    n = 30000
+    o = (rng.uniform(-0.95, 0.95, (n, 3))).astype(np.float32).astype(np.float64)
+    dirs = rng.normal(size=(n, 3))
+    # a third of the rays aim at points ON a shared diagonal (of a wall, of the tilted rectangle)
+    tvv = tv.reshape(-1, 3, 3)
+    for i in range(0, n, 3):
+        t = int(rng.integers(0, len(tvv)))
+        s = rng.uniform(0, 1)
+        target = tvv[t][0] * (1 - s) + tvv[t][2] * s if rng.uniform() < 0.5 else tvv[t][0] * (1 - s) + tvv[t][1] * s
+        dirs[i] = target - o[i]
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    want = h.oracle_intersect(sc, o, dirs)
+    backend.set_scene(sc)
+    merged = backend.intersect(o, dirs)
+    _check_hits(merged, want)
+    monkeypatch.setenv("RAYTRACING_AMD_NO_QUADS", "1")
+    backend.set_scene(sc)
+    plain = backend.intersect(o, dirs)
+    monkeypatch.delenv("RAYTRACING_AMD_NO_QUADS")
+    _check_hits(plain, want)
+    assert np.array_equal(merged["gprim"], plain["gprim"])
+    # rendering through either table gives the same image up to which hits get refined in double
+    imgs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("RAYTRACING_AMD_NO_QUADS", "1")
+        backend.set_scene(sc)
+        backend.resize(96, 54)
+        backend.render(96, 54, 0, 4, 6, 5)
+        backend.synchronize()
+        imgs.append(backend.read())
+        if off:
+            monkeypatch.delenv("RAYTRACING_AMD_NO_QUADS")
+    differing = (np.abs(imgs[0] - imgs[1]).max(axis=2) > 1e-4 * 4).mean()
+    assert differing < 5e-3, differing
