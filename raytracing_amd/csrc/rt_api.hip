@@ -21,6 +21,7 @@
 #include "rt_filter.h"
 #include "rt_render.h"
 #include "rt_scene.h"
+#include "rt_wavefront.h"
 
 using namespace rt;
 
@@ -65,6 +66,7 @@ struct rt_ctx {
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
+    DevBuf wf_rays[2], wf_paths, wf_hits, wf_radiance, wf_counters, wf_partials;   // wavefront form (hierarchy scenes)
     DevBuf ray_dir, ray_res; int ray_w = 0, ray_h = 0;   // camera-ray table of the current scene at ray_w x ray_h
     std::vector<EventPair> timed;        // recorded around render launches, not yet read
     std::vector<EventPair> spare_events; // read and ready for reuse (events are created once, not per launch)
@@ -631,6 +633,85 @@ int rt_accum_read(rt_ctx *c, float *host) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// render, wavefront form (see rt_wavefront.h): scenes searched through the hierarchy
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+int render_wavefront(rt_ctx *c, const rt_render_params *p, float *accum, hipStream_t stream) {
+    const long long rect_px = (long long)(p->x1 - p->x0) * (p->y1 - p->y0);
+    // paths in flight per batch: enough that even the last, sparsely populated segments fill the GPU
+    long long target = 16ll << 20;
+    if (const char *e = std::getenv("RAYTRACING_AMD_WF_PATHS")) target = std::max(1ll << 16, std::atoll(e));
+    const int batch_cap = (int)std::max<long long>(1, std::min<long long>(p->sample_count, target / rect_px));
+    const size_t cap_paths = (size_t)rect_px * batch_cap;
+    if (cap_paths >= (1ull << 31)) return fail(c, RT_ERR_INVALID_ARG, "rt_render: rectangle too large for one wavefront batch");
+    const int n_seg = p->max_bounces + 1;
+    bool grow = false;
+    for (int k = 0; k < 2; ++k) grow = grow || cap_paths * sizeof(WfRay) > c->wf_rays[k].bytes;
+    const size_t n_part_rows = (cap_paths + 255) / 256;
+    grow = grow || cap_paths * sizeof(WfPath) > c->wf_paths.bytes || (size_t)(2 * (n_seg + 1)) * 4 > c->wf_counters.bytes ||
+           n_part_rows * kStatCount * 8 > c->wf_partials.bytes;
+    if (grow) {
+        HIP_TRY(c, hipDeviceSynchronize());   // earlier launches may still use the old buffers
+        for (int k = 0; k < 2; ++k) HIP_TRY(c, c->wf_rays[k].ensure(cap_paths * sizeof(WfRay)));
+        HIP_TRY(c, c->wf_paths.ensure(cap_paths * sizeof(WfPath)));
+        HIP_TRY(c, c->wf_hits.ensure(cap_paths * sizeof(WfHit)));
+        HIP_TRY(c, c->wf_radiance.ensure(cap_paths * 3 * sizeof(float)));
+        HIP_TRY(c, c->wf_counters.ensure((size_t)(2 * (64 + 1)) * 4));
+        HIP_TRY(c, c->wf_partials.ensure(n_part_rows * kStatCount * 8));
+        HIP_TRY(c, hipMemset(c->wf_partials.p, 0, c->wf_partials.bytes));
+    }
+    if (int st = ensure_ray_table(c, p->width, p->height, stream)) return st;
+
+    EventPair ev;
+    bool have_ev = false;
+    { std::lock_guard<std::mutex> g(c->mu); if (!c->spare_events.empty()) { ev = c->spare_events.back(); c->spare_events.pop_back(); have_ev = true; } }
+    if (!have_ev) { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
+    HIP_TRY(c, hipEventRecord(ev.a, stream));
+    const DevScene S = c->S;
+    uint32_t *counts = c->wf_counters.as<uint32_t>();          // [n_seg + 1] rays queued per segment
+    uint32_t *cursors = counts + (64 + 1);                      // [n_seg] extend's read position per segment
+    for (int s0 = 0; s0 < p->sample_count; s0 += batch_cap) {
+        const int bs = std::min(batch_cap, p->sample_count - s0);
+        WfArgs A{};
+        A.width = p->width; A.height = p->height; A.x0 = p->x0; A.y0 = p->y0; A.rect_w = p->x1 - p->x0; A.rect_h = p->y1 - p->y0;
+        A.ray_dir = c->ray_dir.as<float>(); A.ray_res = c->ray_res.as<float>();
+        A.sample_begin = p->sample_begin + s0; A.batch_samples = bs; A.n_paths = (uint32_t)(rect_px * bs);
+        A.div_samples = make_fast_div((uint32_t)bs); A.div_rect_h = make_fast_div((uint32_t)A.rect_h);
+        A.max_bounces = p->max_bounces; A.seed_lo = (uint32_t)p->seed; A.seed_hi = (uint32_t)(p->seed >> 32);
+        A.paths = c->wf_paths.as<WfPath>(); A.hits = c->wf_hits.as<WfHit>(); A.radiance = c->wf_radiance.as<float>();
+        A.accum = accum; A.stats = c->stats.as<unsigned long long>(); A.partials = c->wf_partials.as<unsigned long long>();
+        HIP_TRY(c, hipMemsetAsync(counts, 0, (size_t)(2 * (64 + 1)) * 4, stream));
+        const unsigned path_blocks = (unsigned)((A.n_paths + 255) / 256);
+        A.rays_in = c->wf_rays[0].as<WfRay>(); A.rays_out = c->wf_rays[1].as<WfRay>();
+        A.count_in = counts; A.count_out = counts + 1; A.cursor = cursors;
+        hipLaunchKernelGGL(k_wf_generate, dim3(path_blocks), dim3(256), 0, stream, S, A);
+        const unsigned extend_blocks = std::min<unsigned>(path_blocks, (unsigned)c->n_cu * 3u);
+        for (int seg = 0; seg < n_seg; ++seg) {
+            A.rays_in = c->wf_rays[seg & 1].as<WfRay>(); A.rays_out = c->wf_rays[(seg + 1) & 1].as<WfRay>();
+            A.count_in = counts + seg; A.count_out = counts + seg + 1; A.cursor = cursors + seg;
+            if (c->has_sph) hipLaunchKernelGGL((k_wf_extend<true>), dim3(extend_blocks), dim3(256), 0, stream, S, A);
+            else hipLaunchKernelGGL((k_wf_extend<false>), dim3(extend_blocks), dim3(256), 0, stream, S, A);
+            hipLaunchKernelGGL(k_wf_shade, dim3(path_blocks), dim3(256), 0, stream, S, A);
+        }
+        hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)((rect_px + 255) / 256)), dim3(256), 0, stream, A);
+        HIP_TRY(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_wf_fold_stats, dim3(1), dim3(256), 0, stream, c->wf_partials.as<unsigned long long>(), (int)n_part_rows,
+                       c->stats.as<unsigned long long>());
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(ev.b, stream));
+    { std::lock_guard<std::mutex> g(c->mu); c->timed.push_back(ev); c->launches++; }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
 // render
 // ---------------------------------------------------------------------------------------------
 int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stream_) {
@@ -652,6 +733,11 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     if (rect_px == 0 || p->sample_count == 0) return RT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = (hipStream_t)stream_;
+    // The wavefront form exists for hierarchy scenes and is selectable, but the single kernel below
+    // is faster on every configuration measured (room + 1.18 M triangles, 1080p: 4.1 against 3.3
+    // G rays/s with 64 M paths in flight, 1.4 with 4 M), so it stays the default.
+    if (c->tri_mode == kTriBvh && std::getenv("RAYTRACING_AMD_WAVEFRONT") != nullptr)
+        return render_wavefront(c, p, accum, stream);
 
     // Job granularity: enough (pixel, chunk) jobs that every resident lane runs many of them, so the
     // end-of-launch tail (lanes waiting for the last jobs) stays a few percent of the launch.

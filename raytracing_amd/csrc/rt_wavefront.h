@@ -1,0 +1,265 @@
+// Wavefront form of the render path for scenes searched through the hierarchy (optional: selected
+// with RAYTRACING_AMD_WAVEFRONT=1; the single kernel of rt_render.h is the default because it
+// measures faster - see the note at the end of this comment).
+//
+// The single render kernel keeps a whole path in registers; every trip of its loop strings a dozen
+// dependent per-lane loads (boxes, leaf rows, the winner's rows, material, sky texel) with only three
+// waves per SIMD to hide them.  Here the path is cut at the closest-hit query:
+//
+//   k_wf_generate   camera rays of a batch of paths (Camera.get_ray, camera.py:39-50)
+//   k_wf_extend     closest hit of every queued ray (Scene.intersect, scene.py:23-27) - a lean,
+//                   persistent kernel: lanes take rays from the queue one by one and walk the
+//                   hierarchy in slices, so a lane whose ray is done takes the next ray at once
+//   k_wf_shade      environment or one bounce per answered ray (renderer.py:39-79); surviving
+//                   paths append their next ray to the other queue, finished ones store radiance
+//   k_wf_resolve    per pixel, adds the batch's path radiances to the accumulation buffer in
+//                   sample order (deterministic: no floating-point atomics anywhere)
+//
+// and the host runs extend + shade once per path segment.  Path state lives in HBM between the
+// kernels (32-byte ray, 32-byte path, 48-byte hit record: ~150 bytes moved per segment, far from
+// the HBM bound).  The device functions - camera_ray, closest hit, path_shade - are the ones the
+// single kernel uses, so both forms trace identical paths.
+//
+// Measured (room + 1.18 M triangles, 1080p, 32 spp, 8 bounces, G rays/s): single kernel 4.1;
+// wavefront 1.4 / 2.7 / 3.3 with 4 M / 16 M / 64 M paths per batch.  Two reasons: every extend
+// launch ends with each wave waiting for its own slowest lanes (amortised only by very large
+// batches), and the extend kernel is not lean - with the double-precision settling code inlined it
+// needs 161 VGPRs, the same three waves per SIMD as the single kernel.  Same-address atomics cost
+// ~8 ns each on this GPU: queue appends and statistics are therefore aggregated per block.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_render.h"
+
+namespace rt {
+
+struct WfRay { float ox, oy, oz; int32_t origin; float dx, dy, dz; uint32_t path; };   // 32 B
+struct WfPath { float tr, tg, tb; uint32_t inside; uint32_t pixel, sample; int32_t depth; uint32_t pad; };   // 32 B
+struct WfHit {   // 48 B
+    float nx, ny, nz; int32_t obj;
+    float px, py, pz; int32_t gprim;
+    uint32_t flags;   // bit 0: contenders settled in double precision, bit 1: winner re-evaluated in double precision
+    uint32_t pad0, pad1, pad2;
+};
+
+struct WfArgs {
+    int32_t width, height, x0, y0, rect_w, rect_h;
+    const float *ray_dir, *ray_res;
+    int32_t sample_begin;        // global index of the batch's first sample
+    int32_t batch_samples;       // samples per pixel in this batch
+    uint32_t n_paths;            // rect_w * rect_h * batch_samples
+    FastDiv div_samples, div_rect_h;
+    int32_t max_bounces;
+    uint32_t seed_lo, seed_hi;
+    WfRay *rays_in, *rays_out;
+    WfPath *paths;
+    WfHit *hits;
+    float *radiance;             // [n_paths][3]
+    uint32_t *count_in, *count_out, *cursor;   // device words: rays queued for this / the next segment, extend's read cursor
+    float *accum;
+    unsigned long long *stats;
+    unsigned long long *partials;   // [blocks][kStatCount] per-block statistics, folded by k_wf_fold_stats (no hot atomics)
+};
+
+// path index -> (pixel of the rectangle, sample of the batch): consecutive paths are the samples of one pixel
+RT_DEV void wf_path_coords(const WfArgs &A, uint32_t p, uint32_t &pixel, uint32_t &sample) {
+    const uint32_t pl = fast_div(p, A.div_samples), j = p - pl * (uint32_t)A.batch_samples;
+    const uint32_t col = fast_div(pl, A.div_rect_h);
+    const int px = A.x0 + (int)col, py = A.y0 + (int)(pl - col * (uint32_t)A.rect_h);
+    pixel = (uint32_t)(px * A.height + py);
+    sample = (uint32_t)A.sample_begin + j;
+}
+
+__global__ __launch_bounds__(256) void k_wf_generate(const DevScene S, const WfArgs A) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.n_paths) return;
+    uint32_t pixel, sample;
+    wf_path_coords(A, p, pixel, sample);
+    Path q;
+    path_begin(S, A.ray_dir, A.ray_res, q, pixel, sample, A.seed_lo, A.seed_hi);
+    WfRay r; r.ox = q.ox; r.oy = q.oy; r.oz = q.oz; r.origin = -1; r.dx = q.dx; r.dy = q.dy; r.dz = q.dz; r.path = p;
+    WfPath s; s.tr = s.tg = s.tb = 1.0f; s.inside = 0; s.pixel = pixel; s.sample = sample; s.depth = 0; s.pad = 0;
+    A.rays_in[p] = r;
+    A.paths[p] = s;
+    if (p == 0) *A.count_in = A.n_paths;
+}
+
+constexpr int kWfSlice = 6;      // boxes per trip of the extend loop
+constexpr int kWfGrab = 256;    // rays a wave reserves from the queue at a time (one atomic each: keep them rare,
+                                 // same-address atomics complete at only ~0.1 G/s)
+
+template <bool HAS_SPH>
+__global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S, const WfArgs A) {
+    constexpr int TRI = kTriBvh;
+    const uint32_t total = *A.count_in;
+    uint32_t win_next = 0, win_end = 0;
+    bool drained = false;
+    bool have = false, walking = false;
+    WfRay ray; ray.ox = ray.oy = ray.oz = 0; ray.dx = ray.dy = 0; ray.dz = 1; ray.origin = -1; ray.path = 0;
+    uint32_t pixel = 0; int32_t depth = 0;
+    typename FirstPass<TRI>::type first;
+    first.init(S);
+    int walk_node = -1;
+    BvhCounters bc; bc.nodes = 0; bc.tris = 0;
+    for (;;) {
+        // ---- idle lanes take the next rays of the queue -------------------------------------------
+        unsigned long long idle = __ballot(!have);
+        while (idle != 0 && !(drained && win_next == win_end)) {
+            if (win_next == win_end) {
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(A.cursor, (uint32_t)kWfGrab);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= total) { drained = true; break; }
+                win_next = base;
+                win_end = base + kWfGrab < total ? base + kWfGrab : total;
+            }
+            const uint32_t avail = win_end - win_next;
+            const uint32_t rk = rank_in(idle);
+            if (!have && rk < avail) {
+                ray = A.rays_in[win_next + rk];
+                const WfPath s = A.paths[ray.path];
+                pixel = s.pixel; depth = s.depth;
+                have = true; walking = false;
+            }
+            const uint32_t want = (uint32_t)__builtin_popcountll(idle);
+            win_next += want < avail ? want : avail;
+            idle = __ballot(!have);
+        }
+        if (__ballot(have) == 0) break;
+        if (have) {
+            const Ray r = make_ray(S, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, ray.origin, depth == 0);
+            RayResidue rr;
+            rr.table = A.ray_res; rr.pixel = pixel; rr.on = (depth == 0) && !S.dof_on;
+            rr.ox = S.cam_res[0]; rr.oy = S.cam_res[1]; rr.oz = S.cam_res[2];
+            if (!walking) {
+                walking = true;
+                walk_node = -1;
+                first.init(S);
+                if (ray_route<TRI>(r) == kRouteFilter) { hit_begin<TRI, HAS_SPH>(S, r, rr, first); walk_node = 0; }
+            }
+            if (walk_node >= 0) search_bvh(S, r, first, bc, walk_node, kWfSlice);
+            if (walk_node < 0) {
+                BvhCounters second_pass; second_pass.nodes = 0; second_pass.tris = 0;
+                const Hit h = hit_finish<TRI, HAS_SPH, false>(S, r, rr, first, second_pass, nullptr);
+                bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
+                WfHit w;
+                w.nx = h.nx; w.ny = h.ny; w.nz = h.nz; w.obj = h.obj;
+                w.px = h.px; w.py = h.py; w.pz = h.pz; w.gprim = h.gprim;
+                w.flags = (h.how == 2 ? 1u : 0u) | (h.refined ? 2u : 0u); w.pad0 = w.pad1 = w.pad2 = 0;
+                A.hits[ray.path] = w;
+                have = false; walking = false;
+            }
+        }
+    }
+    // statistics: per-block sums into the block's own row of `partials` (launches on one stream
+    // run one after another, so a plain read-modify-write is safe)
+    __shared__ unsigned long long sh_nodes[4], sh_tris[4];
+    unsigned long long nodes = bc.nodes, tris = bc.tris;
+    for (int off = 32; off > 0; off >>= 1) { nodes += __shfl_down(nodes, off, 64); tris += __shfl_down(tris, off, 64); }
+    const int wave = threadIdx.x >> 6;
+    if (lane_id() == 0) { sh_nodes[wave] = nodes; sh_tris[wave] = tris; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *row = A.partials + (size_t)blockIdx.x * kStatCount;
+        row[kStatBvhNodes] += sh_nodes[0] + sh_nodes[1] + sh_nodes[2] + sh_nodes[3];
+        row[kStatTriTests] += sh_tris[0] + sh_tris[1] + sh_tris[2] + sh_tris[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wf_shade(const DevScene S, const WfArgs A) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = *A.count_in;
+    const bool live = i < total;
+    bool alive = false, f_exact = false, f_refine = false, f_sky = false, f_shaded = false, f_done = false;
+    WfRay next; next.ox = next.oy = next.oz = 0; next.dx = next.dy = next.dz = 0; next.origin = -1; next.path = 0;
+    if (live) {
+        const WfRay ray = A.rays_in[i];
+        const WfPath s = A.paths[ray.path];
+        const WfHit w = A.hits[ray.path];
+        Path p;
+        p.ox = ray.ox; p.oy = ray.oy; p.oz = ray.oz; p.dx = ray.dx; p.dy = ray.dy; p.dz = ray.dz;
+        p.tr = s.tr; p.tg = s.tg; p.tb = s.tb;
+        p.key0 = s.pixel ^ A.seed_lo; p.key1 = s.sample ^ A.seed_hi;
+        p.depth = s.depth; p.origin = ray.origin; p.inside = s.inside != 0; p.pixel = s.pixel;
+        Hit h;
+        h.obj = w.obj; h.prim = 0; h.gprim = w.gprim; h.t = 0; h.nx = w.nx; h.ny = w.ny; h.nz = w.nz;
+        h.px = w.px; h.py = w.py; h.pz = w.pz; h.how = 0; h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0;
+        float er, eg, eb;
+        alive = path_shade(S, p, A.max_bounces, h, er, eg, eb);
+        f_exact = (w.flags & 1u) != 0; f_refine = (w.flags & 2u) != 0; f_sky = w.obj < 0; f_shaded = w.obj >= 0;
+        if (alive) {
+            WfPath t = s;
+            t.tr = p.tr; t.tg = p.tg; t.tb = p.tb; t.depth = p.depth; t.inside = p.inside ? 1u : 0u;
+            A.paths[ray.path] = t;
+            next.ox = p.ox; next.oy = p.oy; next.oz = p.oz; next.origin = p.origin;
+            next.dx = p.dx; next.dy = p.dy; next.dz = p.dz; next.path = ray.path;
+        } else {
+            float *dst = A.radiance + 3 * (size_t)ray.path;
+            dst[0] = p.tr * er; dst[1] = p.tg * eg; dst[2] = p.tb * eb;
+            f_done = true;
+        }
+    }
+    // surviving paths append their next ray: one counter update per BLOCK
+    __shared__ uint32_t sh_keep[4], sh_base;
+    __shared__ uint32_t sh_stat[4][6];
+    const int wave = threadIdx.x >> 6;
+    const unsigned long long keep = __ballot(alive);
+    const uint32_t n_ray = (uint32_t)__builtin_popcountll(__ballot(live));
+    const uint32_t n_exact = (uint32_t)__builtin_popcountll(__ballot(f_exact)), n_refine = (uint32_t)__builtin_popcountll(__ballot(f_refine));
+    const uint32_t n_sky = (uint32_t)__builtin_popcountll(__ballot(f_sky)), n_shaded = (uint32_t)__builtin_popcountll(__ballot(f_shaded));
+    const uint32_t n_done = (uint32_t)__builtin_popcountll(__ballot(f_done));
+    if (lane_id() == 0) {
+        sh_keep[wave] = (uint32_t)__builtin_popcountll(keep);
+        sh_stat[wave][0] = n_ray; sh_stat[wave][1] = n_exact; sh_stat[wave][2] = n_refine;
+        sh_stat[wave][3] = n_sky; sh_stat[wave][4] = n_shaded; sh_stat[wave][5] = n_done;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n_keep = sh_keep[0] + sh_keep[1] + sh_keep[2] + sh_keep[3];
+        sh_base = n_keep ? atomicAdd(A.count_out, n_keep) : 0u;
+        uint32_t t[6];
+        for (int k = 0; k < 6; ++k) t[k] = sh_stat[0][k] + sh_stat[1][k] + sh_stat[2][k] + sh_stat[3][k];
+        if (t[0]) {
+            unsigned long long *row = A.partials + (size_t)blockIdx.x * kStatCount;
+            row[kStatRays] += t[0];
+            row[kStatSphTests] += (unsigned long long)t[0] * (uint32_t)(S.n_sph_rows + S.n_big_sph);
+            row[kStatTriTests] += (unsigned long long)t[0] * (uint32_t)S.n_tri_rows;
+            row[kStatExact] += t[1]; row[kStatRefine] += t[2]; row[kStatSky] += t[3]; row[kStatShaded] += t[4]; row[kStatPaths] += t[5];
+        }
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += sh_keep[w];
+        A.rays_out[sh_base + before + rank_in(keep)] = next;
+    }
+}
+
+// Folds the per-block statistics rows into the context's counters and clears them.
+__global__ __launch_bounds__(256) void k_wf_fold_stats(unsigned long long *partials, int n_rows, unsigned long long *stats) {
+    __shared__ unsigned long long sh[256];
+    for (int k = 0; k < kStatCount; ++k) {
+        unsigned long long v = 0;
+        for (int r = threadIdx.x; r < n_rows; r += 256) { v += partials[(size_t)r * kStatCount + k]; partials[(size_t)r * kStatCount + k] = 0; }
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
+        if (threadIdx.x == 0 && sh[0]) atomicAdd(stats + k, sh[0]);
+        __syncthreads();
+    }
+}
+
+// Adds the batch's path radiances to the accumulation buffer, per pixel, in sample order.
+__global__ __launch_bounds__(256) void k_wf_resolve(const WfArgs A) {
+    const uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pl >= (uint32_t)(A.rect_w * A.rect_h)) return;
+    const uint32_t col = fast_div(pl, A.div_rect_h);
+    const int px = A.x0 + (int)col, py = A.y0 + (int)(pl - col * (uint32_t)A.rect_h);
+    float r = 0, g = 0, b = 0;
+    const float *src = A.radiance + 3 * (size_t)pl * (size_t)A.batch_samples;
+    for (int j = 0; j < A.batch_samples; ++j) { r += src[3 * j]; g += src[3 * j + 1]; b += src[3 * j + 2]; }
+    float *dst = A.accum + 3 * ((size_t)px * A.height + py);
+    dst[0] += r; dst[1] += g; dst[2] += b;
+}
+
+}  // namespace rt

@@ -10,7 +10,7 @@ W, H = 1920, 1080
 base = h.packed_scene("room_horse")
 cases = [(0, False, 16), (0, True, 16), (2, True, 8), (4, True, 8), (6, True, 8)]
 if len(sys.argv) > 1:
-    cases = [(int(a), True, 8) for a in sys.argv[1:]]
+    cases = [(int(a), True, int(os.environ.get('SPP', 8))) for a in sys.argv[1:]]
 for lv, bvh, spp in cases:
     sc = base.with_subdivided_mesh(base.n_meshes - 1, lv) if lv else base
     sc = dataclasses.replace(sc, library_bvh=bvh)

@@ -211,3 +211,28 @@ def test_progressive_batches_and_device_tonemap(backend):
     host = pp.process(previews[-1].cpu().numpy().astype(np.float64))
     assert np.abs(dev.cpu().numpy() - host).max() < 2e-5
     assert float(previews[0].mean()) > 0 and len(previews) == 3
+
+
+def test_wavefront_form_traces_the_same_paths(backend, monkeypatch):
+    """The optional wavefront form (generate / extend / shade / resolve kernels) runs the same device
+    functions as the single render kernel, so images agree up to float32 summation order and the
+    statistics are identical."""
+    base = h.packed_scene("room_horse")
+    backend.set_scene(base.with_subdivided_mesh(base.n_meshes - 1, 3))
+    W, H, spp, b = 96, 54, 6, 5
+    out = []
+    for wf in (False, True):
+        if wf:
+            monkeypatch.setenv("RAYTRACING_AMD_WAVEFRONT", "1")
+            monkeypatch.setenv("RAYTRACING_AMD_WF_PATHS", "65536")     # several batches
+        backend.resize(W, H)
+        backend.reset_stats()
+        backend.render(W, H, 2, spp, b, 11)
+        backend.synchronize()
+        out.append((backend.read(), backend.stats()))
+    monkeypatch.delenv("RAYTRACING_AMD_WAVEFRONT")
+    monkeypatch.delenv("RAYTRACING_AMD_WF_PATHS")
+    (a, sa), (w, sw) = out
+    assert np.allclose(a, w, rtol=1e-5, atol=1e-6), np.abs(a - w).max()
+    for k in ("rays", "paths", "tri_tests", "sphere_tests", "bvh_node_tests", "exact_rays", "refined_hits", "sky_lookups", "shaded_hits"):
+        assert sa[k] == sw[k], (k, sa[k], sw[k])
