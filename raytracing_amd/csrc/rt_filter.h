@@ -394,10 +394,8 @@ RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters 
         if (leaf < 0) break;
         const int first = leaf >> 4, cnt = leaf & 15;
         bc.tris += (uint32_t)cnt;
-        TriRow T = load_tri_row_lane(rows, first);
         for (int k = 0; k < cnt; ++k) {
-            const TriRow cur = T;
-            if (k + 1 < cnt) T = load_tri_row_lane(rows, first + k + 1);   // in flight while `cur` is tested
+            const TriRow cur = load_tri_row_lane(rows, first + k);
             float sure_thi;
             const float tl = tri_tlo<true>(cur, r, &sure_thi);
             sink.certain_hit(sure_thi);
