@@ -137,6 +137,19 @@ const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: last error of 
 int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_bvh_node *nodes_out,
                  int32_t nodes_capacity, int32_t *tri_index_out, int32_t *n_nodes_out);
 
+/* Host-side Wavefront OBJ reader with the semantics of Mesh.load_from_obj_file
+ * (src/mesh/mesh.py:211-251): one object per "o" record, first index of each a/b/c corner, face
+ * indices rebased by the vertex count of earlier objects, fan triangulation.  CPU only.
+ * rt_obj_open parses the file and reports the sizes; rt_obj_read copies into caller arrays:
+ * names[n_objects][name_stride] (NUL-terminated, truncated), vertex_begin / tri_begin[n_objects+1],
+ * vertices[n_vertices][3], triangles[n_triangles][3] (indices local to their object); any pointer
+ * may be NULL.  On failure rt_last_error(NULL) has the reason. */
+typedef struct rt_obj rt_obj;
+int rt_obj_open(const char *path, rt_obj **out, int32_t *n_objects, int64_t *n_vertices, int64_t *n_triangles);
+int rt_obj_read(const rt_obj *obj, char *names, int32_t name_stride, int64_t *vertex_begin, int64_t *tri_begin,
+                double *vertices, int32_t *triangles);
+int rt_obj_close(rt_obj *obj);
+
 /* Scene upload: what Renderer.init_render binds (renderer.py:81-88, `self.scene = ...SCENE`). */
 int rt_set_scene(rt_ctx *ctx, const rt_scene_desc *scene);
 

@@ -24,7 +24,7 @@ RT_ERR_STOPPED = 5
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
            "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms",
-           "rt_debug_trace_paths", "rt_build_bvh"]
+           "rt_debug_trace_paths", "rt_build_bvh", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
 
 class RtRenderParams(C.Structure):
@@ -86,6 +86,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_debug_trace_paths.argtypes = [vp, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                          fp, ip, ip, ip, ip, fp, fp, fp]
     lib.rt_build_bvh.argtypes = [C.c_int32, dp, C.c_int32, vp, C.c_int32, ip, ip]
+    lp = C.POINTER(C.c_int64)
+    lib.rt_obj_open.argtypes = [C.c_char_p, C.POINTER(vp), ip, lp, lp]
+    lib.rt_obj_read.argtypes = [vp, C.c_char_p, C.c_int32, lp, lp, dp, ip]
+    lib.rt_obj_close.argtypes = [vp]
     if path is None:
         _lib = lib
     return lib

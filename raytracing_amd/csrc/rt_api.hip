@@ -19,6 +19,7 @@
 #include "rt_bvh_build.h"
 #include "rt_exact.h"
 #include "rt_filter.h"
+#include "rt_obj.h"
 #include "rt_render.h"
 #include "rt_scene.h"
 #include "rt_wavefront.h"
@@ -150,6 +151,38 @@ int rt_destroy(rt_ctx *ctx) {
     delete ctx;
     return RT_OK;
 }
+
+struct rt_obj { ObjFile f; };
+
+int rt_obj_open(const char *path, rt_obj **out, int32_t *n_objects, int64_t *n_vertices, int64_t *n_triangles) {
+    if (!path || !out) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    rt_obj *o = new rt_obj();
+    if (!parse_obj(path, o->f)) { g_create_error = o->f.error; delete o; return RT_ERR_INVALID_ARG; }
+    if (n_objects) *n_objects = (int32_t)o->f.names.size();
+    if (n_vertices) *n_vertices = (int64_t)o->f.vertices.size() / 3;
+    if (n_triangles) *n_triangles = (int64_t)o->f.triangles.size() / 3;
+    *out = o;
+    return RT_OK;
+}
+
+int rt_obj_read(const rt_obj *o, char *names, int32_t name_stride, int64_t *vertex_begin, int64_t *tri_begin, double *vertices,
+                int32_t *triangles) {
+    if (!o) return RT_ERR_INVALID_ARG;
+    const size_t n = o->f.names.size();
+    if (names && name_stride > 0)
+        for (size_t i = 0; i < n; ++i) {
+            std::memset(names + i * (size_t)name_stride, 0, (size_t)name_stride);
+            std::memcpy(names + i * (size_t)name_stride, o->f.names[i].data(), std::min<size_t>(o->f.names[i].size(), (size_t)name_stride - 1));
+        }
+    if (vertex_begin) std::memcpy(vertex_begin, o->f.vertex_begin.data(), sizeof(int64_t) * (n ? n + 1 : 1));
+    if (tri_begin) std::memcpy(tri_begin, o->f.tri_begin.data(), sizeof(int64_t) * (n ? n + 1 : 1));
+    if (vertices && !o->f.vertices.empty()) std::memcpy(vertices, o->f.vertices.data(), sizeof(double) * o->f.vertices.size());
+    if (triangles && !o->f.triangles.empty()) std::memcpy(triangles, o->f.triangles.data(), sizeof(int32_t) * o->f.triangles.size());
+    return RT_OK;
+}
+
+int rt_obj_close(rt_obj *o) { delete o; return RT_OK; }
 
 int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_bvh_node *nodes_out, int32_t nodes_capacity,
                  int32_t *tri_index_out, int32_t *n_nodes_out) {

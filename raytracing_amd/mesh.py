@@ -151,17 +151,11 @@ class Mesh(ObjectBase):
         self.update_transformed_vertices()
 
     # -- OBJ loading (mesh.py:211-251) ---------------------------------------------------------
-    @classmethod
-    def load_from_obj_file(cls, path: str) -> List["Mesh"]:
-        """One ``Mesh`` per ``o`` record, in file order.
-
-        Semantics kept from upstream because they define object and face numbering: only ``o``,
-        ``v`` and ``f`` records are read; a face corner ``a/b/c`` contributes its first index; face
-        indices are rebased by the number of vertices of all earlier objects; polygons are
-        fan-triangulated around their first corner; records before the first ``o`` are collected
-        but dropped if no object ever starts.
-        """
-        groups: list[tuple[str, list, list]] = []  # (name, vertices, triangles)
+    @staticmethod
+    def _parse_obj_python(path: str) -> list:
+        """[(name, vertices, triangles)] per ``o`` record: the plain-Python statement of the
+        semantics (used when the native library is not built, and as the yardstick in the tests)."""
+        groups: list = []
         verts: list = []
         tris: list = []
         offset = 0
@@ -184,6 +178,53 @@ class Mesh(ObjectBase):
                         tris.append((idx[0], idx[k], idx[k + 1]))
         if groups:
             groups[-1] = (groups[-1][0], verts, tris)
+        return groups
+
+    @staticmethod
+    def _parse_obj_native(path: str):
+        """Same result from the C++ reader in the HIP library (rt_obj_open / rt_obj_read: host code,
+        needs no GPU); None when the library is not built."""
+        import ctypes as C
+
+        try:
+            from .backend.lib import load_library
+
+            lib = load_library()
+        except Exception:
+            return None
+        handle = C.c_void_p()
+        n_obj, n_v, n_t = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        st = lib.rt_obj_open(str(path).encode(), C.byref(handle), C.byref(n_obj), C.byref(n_v), C.byref(n_t))
+        if st != 0:
+            raise ValueError((lib.rt_last_error(None) or b"").decode() or f"cannot read {path}")
+        try:
+            n = n_obj.value
+            stride = 256
+            names = C.create_string_buffer(max(n, 1) * stride)
+            vb = np.zeros(n + 1, np.int64)
+            tb = np.zeros(n + 1, np.int64)
+            v = np.zeros((n_v.value, 3), np.float64)
+            t = np.zeros((n_t.value, 3), np.int32)
+            lib.rt_obj_read(handle, names, stride, vb.ctypes.data_as(C.POINTER(C.c_int64)), tb.ctypes.data_as(C.POINTER(C.c_int64)),
+                            v.ctypes.data_as(C.POINTER(C.c_double)), t.ctypes.data_as(C.POINTER(C.c_int32)))
+        finally:
+            lib.rt_obj_close(handle)
+        return [(names.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode(), v[vb[i]:vb[i + 1]], t[tb[i]:tb[i + 1]])
+                for i in range(n)]
+
+    @classmethod
+    def load_from_obj_file(cls, path: str) -> List["Mesh"]:
+        """One ``Mesh`` per ``o`` record, in file order.
+
+        Semantics kept from upstream because they define object and face numbering: only ``o``,
+        ``v`` and ``f`` records are read; a face corner ``a/b/c`` contributes its first index; face
+        indices are rebased by the number of vertices of all earlier objects; polygons are
+        fan-triangulated around their first corner; records before the first ``o`` are collected
+        but dropped if no object ever starts.
+        """
+        groups = cls._parse_obj_native(path)
+        if groups is None:
+            groups = cls._parse_obj_python(path)
         meshes: List[Mesh] = []
         for name, v, t in groups:
             m = cls(Material.default_material(), Vec3(0), np.asarray(v, dtype=np.float64).reshape(-1, 3),

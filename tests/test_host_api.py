@@ -226,3 +226,31 @@ def test_subdivision_keeps_the_surface():
     assert np.array_equal(fine.tri_verts[:f0], base.tri_verts[:b0])
     v = fine.tri_verts[f0:f1].reshape(-1, 3)
     assert np.all(v.min(0) >= base.mesh_aabb[m][:3]) and np.all(v.max(0) <= base.mesh_aabb[m][3:])
+
+
+def test_native_obj_reader_equals_the_python_statement(tmp_path):
+    """rt_obj_open / rt_obj_read (C++ host code in the library) against the plain-Python statement of
+    upstream's loader semantics (mesh.py:211-251), quirks included: records before the first `o`
+    land in the first object, face indices are rebased by the vertices of EARLIER objects only,
+    corners a/b/c and a//c, polygons fanned, short faces dropped, CRLF and indentation stripped,
+    `vn` / `vt` / comments ignored; a file without `o` gives no mesh."""
+    text = ("# comment\r\nv 9 9 9\nf 1 2 3\n\n  o first thing  \nv 0 0 0\nv 1 0 0\n\tv 1 1 0\nvn 0 0 1\nvt 0.5 0.5\n"
+            "f 1/1/1 2/2/1 3/3/1 4/4/1 2\nf 1 2\no second\nv 0 0 1e0\nv 1.5e-3 -0 1\nv -0.25 1 1\ns off\nf 5//1 6//1 7//1\n"
+            "usemtl x\nf 7 6 5 5\no empty\n")
+    p = tmp_path / "quirks.obj"
+    p.write_text(text)
+    native = mesh.Mesh._parse_obj_native(str(p))
+    plain = mesh.Mesh._parse_obj_python(str(p))
+    assert native is not None and [g[0] for g in native] == [g[0] for g in plain] == ["first thing", "second", "empty"]
+    for (_, va, ta), (_, vb, tb) in zip(native, plain):
+        assert np.array_equal(va, np.asarray(vb, np.float64).reshape(-1, 3))
+        assert np.array_equal(ta, np.asarray(tb, np.int32).reshape(-1, 3))
+    assert native[0][2].tolist() == [[0, 1, 2], [0, 1, 2], [0, 2, 3], [0, 3, 1]]   # the stray face, then the fanned pentagon
+    assert native[1][2].tolist() == [[0, 1, 2], [2, 1, 0], [2, 0, 0]] and len(native[2][1]) == 0
+    ms = mesh.Mesh.load_from_obj_file(str(p))
+    assert [m.name for m in ms] == ["first thing", "second", "empty"] and ms[2].bounding_box is None
+    q = tmp_path / "no_objects.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    assert mesh.Mesh.load_from_obj_file(str(q)) == [] and mesh.Mesh._parse_obj_native(str(q)) == []
+    with pytest.raises(ValueError):
+        mesh.Mesh._parse_obj_native(str(tmp_path / "missing.obj"))
