@@ -13,7 +13,7 @@ sky image are resident in HBM before the timed region starts.
 
 Prints ONE JSON line on rank 0, with
   roofline     - float32 VALU roofline of the render kernel: algorithmic FLOPs (tests executed x
-                 fixed per-test constants) / kernel time from HIP events recorded
+                 fixed per-test constants, listed below) / kernel time from HIP events recorded
                  on the launch stream, against the 157.3 TFLOP/s vector peak
   cpu_baseline - the double-precision CPU restatement (oracle/rt_oracle.c) of the same path,
                  timed on this host on a bounded sample of the same workload.
@@ -34,7 +34,10 @@ sys.path.insert(0, REPO)
 
 WIDTH, HEIGHT, SPP, BOUNCES, SEED = 1920, 1080, 256, 8, 2025
 PEAK_FP32_VALU_TFLOPS = 157.3
-# algorithmic FLOPs per unit of work (FMA = 2; see DESIGN.md "FLOP accounting")
+# Algorithmic FLOPs per unit of work (FMA = 2, every other arithmetic op or compare = 1, loop
+# invariants hoisted): ray-sphere test 20 (sphere.py:15-20), + 12 when the discriminant is not
+# negative, ray-triangle test 46 (mesh.py:122-136 with ab, ac, N precomputed), one bounce 120
+# (renderer.py:39-79 + hit point / normal), one camera ray 40 (camera.py:40-49), one sky lookup 20.
 F_SPHERE, F_SPHERE_HIT, F_TRI, F_SHADE, F_RAYGEN, F_SKY = 20, 12, 46, 120, 40, 20
 
 

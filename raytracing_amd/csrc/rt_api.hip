@@ -58,7 +58,7 @@ struct rt_ctx {
     int device = 0;
     int n_cu = 256;
     std::mutex mu;               // guards err and the host-side stats bookkeeping
-    std::string err;
+    char err[512] = {0};         // fixed storage: rt_last_error hands out this address, which never moves
     std::atomic<int> stop{0};
     bool has_scene = false;
     DevScene S{};
@@ -79,7 +79,7 @@ namespace {
 int fail(rt_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (c) { std::lock_guard<std::mutex> g(c->mu); c->err = buf; } else g_create_error = buf;
+    if (c) { std::lock_guard<std::mutex> g(c->mu); std::memcpy(c->err, buf, sizeof c->err); c->err[sizeof c->err - 1] = 0; } else g_create_error = buf;
     return code;
 }
 
@@ -116,7 +116,7 @@ int rt_abi_version(void) { return RT_ABI_VERSION; }
 
 const char *rt_last_error(const rt_ctx *ctx) {
     if (!ctx) return g_create_error.c_str();
-    return ctx->err.c_str();
+    return ctx->err;
 }
 
 int rt_create(int device_id, rt_ctx **out) {

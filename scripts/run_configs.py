@@ -1,5 +1,4 @@
-"""Measures the BASELINE configurations other than the bench.py headline on one GPU (developer tool;
-the numbers go into DESIGN.md).  Usage: python scripts/run_configs.py [c2] [c4] [c5] [--spp-scale F]"""
+"""Measures the BASELINE configurations other than the bench.py headline on one GPU (developer tool).  Usage: python scripts/run_configs.py [c2] [c4] [c5] [--spp-scale F]"""
 import sys, os, time, dataclasses
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
