@@ -80,6 +80,11 @@ constexpr float kTCertain = 1e-9f;           // a depth bound above this certain
 // double-precision division whenever any of its 64 lanes grazes (measured: 13 % of kernel time).
 constexpr float kRelAcceptStrict = 9.5e-6f;
 constexpr float kRelAcceptRender = 2e-4f;
+// For a SHORT ray (a bounce that lands close to where it started) a relative bound is the wrong yardstick:
+// what the next segment sees is the absolute position of the hit, and every float32 hit position already
+// carries an error of ~1e-7 of the scene size.  The render kernel therefore also accepts a depth whose
+// error bound, as a distance, is below this fraction of the scene size (|o| + scene radius).
+constexpr float kAbsAcceptRender = 1e-5f;
 
 // A ray prepared for the filter.  All bounds assume 1/2 <= |d| <= 2 and no exactly-zero component
 // of d (such rays go straight to the exact code: see ray_needs_exact).
@@ -408,14 +413,14 @@ RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters 
 // 2 undecided (ask the exact code about this primitive).
 struct Verdict { int status; float t, thi; };
 
-RT_DEV Verdict judge_tri(const DevScene &S, int32_t ti, const Ray &r, float rel_accept) {
+RT_DEV Verdict judge_tri(const DevScene &S, int32_t ti, const Ray &r, float rel_accept, float abs_accept) {
     const TriRow T = S.tri_by_id[ti];
     TriEval e = tri_eval(T, r);
     float bb = e.g * T.cb, bt = e.g * T.ct;
     bool certain = (e.m - bb >= 0.0f) && (e.t - bt > kTCertain) && (abs_(e.nd) >= S.tri_aux[ti].det_hi);
     Verdict v;
     v.t = e.t; v.thi = e.t + bt;
-    v.status = !certain ? 2 : ((bt <= rel_accept * e.t) ? 0 : 1);
+    v.status = !certain ? 2 : ((bt <= max_(rel_accept * e.t, abs_accept)) ? 0 : 1);
     return v;
 }
 
@@ -501,7 +506,7 @@ RT_DEV void search_big_spheres(const DevScene &S, const Ray &r, D3 o64, D3 d64, 
 
 struct SphVerdict { int status; int root; float t, thi; };
 
-RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r, float rel_accept) {
+RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r, float rel_accept, float abs_accept) {
     const SphRow P = S.sph_by_id[si];
     SphBounds o = sphere_bounds(P, r);
     SphVerdict v; v.status = 2; v.root = 0; v.t = 0; v.thi = 0;
@@ -520,7 +525,7 @@ RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r, floa
     // precise enough?  depth to rel_accept relative, and the normal (pos - c)/r to rel_accept
     float half = 0.5f * (hi - lo);
     float perr = half * r.dlen + 3.0f * kU * (r.o2 + P.cn + t * r.dlen) * 1.75f;
-    bool precise = (half <= rel_accept * t) && (perr <= rel_accept * P.r);
+    bool precise = (half <= max_(rel_accept * t, abs_accept)) && (perr <= rel_accept * P.r);
     v.status = precise ? 0 : 1;
     return v;
 }
@@ -631,6 +636,8 @@ RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, cons
     const bool scan = route == kRouteScan;
     bool second = route == kRouteOpen; float limit = kInf; int32_t skip = -1;
     int32_t gprim = -1; int root = 0; float t = kInf;
+    // absolute depth tolerance of the render kernel (see kAbsAcceptRender); none for the closest-hit entry
+    const float abs_accept = STRICT ? 0.0f : kAbsAcceptRender * (r.o2 + S.scene_radius);
     if (route == kRouteFilter) {
         if (first.any()) {
             gprim = first.best_id();
@@ -638,10 +645,10 @@ RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, cons
             const bool has_second = first.has_second();
             int status; float thi;
             if (gprim < S.n_spheres) {
-                SphVerdict v = judge_sphere(S, gprim, r, STRICT ? kRelAcceptStrict : kRelAcceptRender);
+                SphVerdict v = judge_sphere(S, gprim, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
                 status = v.status; t = v.t; thi = v.thi; root = v.root;
             } else {
-                Verdict v = judge_tri(S, gprim - S.n_spheres, r, STRICT ? kRelAcceptStrict : kRelAcceptRender);
+                Verdict v = judge_tri(S, gprim - S.n_spheres, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
                 status = v.status; t = v.t; thi = v.thi;
             }
             skip = gprim;
