@@ -121,6 +121,25 @@ RT_DEV ExactHit exact_single(const DevScene &S, int32_t gprim, D3 o, D3 d, int32
     return exact_tri(C.tri64 + 9 * (size_t)ti, o, d);
 }
 
+// Depth only of one primitive by global id (same arithmetic as exact_single, so the same depth);
+// hit = false when upstream would not report it.
+struct ExactDepth { bool hit; double t; };
+
+RT_DEV ExactDepth exact_single_depth(const DevScene &S, int32_t gprim, D3 o, D3 d, int32_t origin) {
+    const ColdScene &C = *S.cold;
+    ExactDepth r; r.hit = false; r.t = 0;
+    ExactHit h;
+    if (gprim < S.n_spheres) h = exact_sphere(C.sph64 + 4 * (size_t)gprim, o, d, gprim == origin, false);
+    else {
+        const int32_t ti = gprim - S.n_spheres;
+        if (gprim == origin) return r;
+        if (!exact_aabb(C.aabb64 + 6 * (size_t)S.tri_aux[ti].mesh, o, d)) return r;
+        h = exact_tri(C.tri64 + 9 * (size_t)ti, o, d, false);
+    }
+    r.hit = h.hit; r.t = h.t;
+    return r;
+}
+
 // Scene.intersect(ray)[0]: first minimum of depth in object order, then per-object hit order.
 // Returns the identity and depth only; the caller re-evaluates the winner for position / normal
 // (same arithmetic, so the same depth).

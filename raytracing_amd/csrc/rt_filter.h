@@ -209,14 +209,15 @@ struct Resolve {
     D3 o, d;
     int32_t origin, skip;      // skip: the first-pass winner, already evaluated
     float limit;
-    ExactHit e; int32_t gprim; uint64_t order;   // best so far; gprim < 0: none
+    double t; int32_t gprim; uint64_t order;   // best so far (depth and identity only; the caller
+                                               // re-evaluates the final winner for position and normal); gprim < 0: none
     RT_DEV void operator()(float tl, int32_t g) {
         if (tl <= limit && tl < kInf && g != skip) {   // +inf = not a candidate (padding rows carry no valid id)
-            const ExactHit x = exact_single(*S, g, o, d, origin);
+            const ExactDepth x = exact_single_depth(*S, g, o, d, origin);
             if (x.hit) {
                 const uint64_t ord = scene_order(*S, g);
-                if (gprim < 0 || x.t < e.t || (x.t == e.t && ord < order)) {
-                    e = x; gprim = g; order = ord;
+                if (gprim < 0 || x.t < t || (x.t == t && ord < order)) {
+                    t = x.t; gprim = g; order = ord;
                     limit = min_(limit, (float)x.t * (1.0f + 2.0f * kU));   // >= x.t
                 }
             }
@@ -679,9 +680,12 @@ RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, cons
         h.how = 2;
         Resolve R;
         R.S = &S; R.o = o64; R.d = d64; R.origin = r.origin; R.skip = skip; R.limit = limit;
-        R.e = e; R.gprim = gprim; R.order = gprim >= 0 ? scene_order(S, gprim) : 0;
+        R.t = e.t; R.gprim = gprim; R.order = gprim >= 0 ? scene_order(S, gprim) : 0;
         search_all<TRI, HAS_SPH>(S, r, o64, d64, R, bc);
-        e = R.e; gprim = R.gprim;
+        if (R.gprim != gprim) {   // someone else won: its position and normal (same arithmetic, same depth)
+            gprim = R.gprim;
+            e = exact_single(S, gprim, o64, d64, r.origin);
+        }
         if (gprim < 0) e.hit = false;
     }
     if (scan) {   // upstream's Scene.intersect, literally, in double precision
