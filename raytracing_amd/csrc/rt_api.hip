@@ -344,6 +344,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         SphRow row{};
         row.cx = (float)ctr.x; row.cy = (float)ctr.y; row.cz = (float)ctr.z;
         row.r2 = (float)(r * r); row.r = (float)r; row.cn = up(norm(ctr)); row.qs = 0; row.gprim = s;
+        row.qs = is_big ? 1.0f : 0.0f;   // marks the huge spheres in the by-id table (the search rows never hold them)
         sph_all[s] = row;
         if (is_big) big.push_back(s);
         else { sph_small.push_back(row); scene_radius = std::max(scene_radius, norm(ctr) + r); }

@@ -622,40 +622,62 @@ RT_DEV void hit_begin(const DevScene &S, const Ray &r, const RayResidue rr, type
     if (TRI != kTriNone) search_tris(S, r, first);   // with a hierarchy: the few scene-sized triangles kept out of it
 }
 
-// Everything after the first pass: judge the winner, settle contenders, build the hit record.
-// `e64`, when given, receives the double-precision record whenever the exact code produced the hit
-// (e64->hit says whether it did).
-template <int TRI, bool HAS_SPH, bool STRICT>
+// Everything after the first pass: judge the winner, settle what float32 could not, build the hit
+// record.  `e64`, when given, receives the double-precision record whenever the exact code produced
+// the hit (e64->hit says whether it did).
+//
+// LEAN = true compiles NO settling code: when the winner needs double precision (or a contender,
+// or the ray itself does), the record comes back with how = kHowUnsettled and nothing else valid.
+// The render path uses this for its first pass over the paths and re-traces the few unsettled ones
+// with the full code - the double-precision code runs for ~0.2 % of the rays, but inlined into the
+// hot kernel its registers cost every ray ~20 %.
+constexpr int kHowUnsettled = 3;
+
+template <int TRI, bool HAS_SPH, bool STRICT, bool LEAN = false>
 RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
                       BvhCounters bc, ExactHit *e64) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
-    h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0;
-    const Ray64 x64 = ray64(r, rr);
-    const D3 o64 = x64.o, d64 = x64.d;
-    ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
+    h.refined = false; h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
     const int route = ray_route<TRI>(r);
-    const bool scan = route == kRouteScan;
-    bool second = route == kRouteOpen; float limit = kInf; int32_t skip = -1;
     int32_t gprim = -1; int root = 0; float t = kInf;
+    int status = 0; float thi = kInf, second_lo = kInf; bool has_second = false;
     // absolute depth tolerance of the render kernel (see kAbsAcceptRender); none for the closest-hit entry
     const float abs_accept = STRICT ? 0.0f : kAbsAcceptRender * (r.o2 + S.scene_radius);
-    if (route == kRouteFilter) {
-        if (first.any()) {
-            gprim = first.best_id();
-            const float second_lo = first.second_lo();
-            const bool has_second = first.has_second();
-            int status; float thi;
-            if (gprim < S.n_spheres) {
+    if (route == kRouteFilter && first.any()) {
+        gprim = first.best_id();
+        second_lo = first.second_lo();
+        has_second = first.has_second();
+        if (gprim < S.n_spheres) {
+            if (HAS_SPH && S.n_big_sph > 0 && S.sph_by_id[gprim].qs != 0.0f) {
+                // a huge sphere: its depth is exact already (double precision, as in the search loop);
+                // position and normal follow in float32 like any other hit's (|pos - c| / r is good
+                // to ~1e-7 however large r is)
+                const Ray64 x = ray64(r, rr);
+                const ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)gprim, x.o, x.d, gprim == r.origin, false);
+                status = eb.hit ? 0 : 2; t = (float)eb.t; thi = t * (1.0f + 2.0f * kU); root = eb.prim;
+            } else {
                 SphVerdict v = judge_sphere(S, gprim, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
                 status = v.status; t = v.t; thi = v.thi; root = v.root;
-            } else {
-                Verdict v = judge_tri(S, gprim - S.n_spheres, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
-                status = v.status; t = v.t; thi = v.thi;
             }
-            skip = gprim;
+        } else {
+            Verdict v = judge_tri(S, gprim - S.n_spheres, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
+            status = v.status; t = v.t; thi = v.thi;
+        }
+    }
+    const bool settle = route != kRouteFilter || (gprim >= 0 && (status != 0 || (has_second && !(second_lo > thi))));
+    ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
+    if (LEAN) {
+        if (settle) { h.how = kHowUnsettled; return h; }
+    } else if (settle) {
+        const Ray64 x64 = ray64(r, rr);
+        const D3 o64 = x64.o, d64 = x64.d;
+        const bool scan = route == kRouteScan;
+        bool second = route == kRouteOpen; float limit = kInf;
+        const int32_t skip = gprim;
+        if (route == kRouteFilter) {
             if (status == 1 && gprim >= S.n_spheres) {
                 // a triangle that is certainly the hit but whose float32 depth is too coarse (grazing
-                // incidence): only the depth is redone in double precision
+                // incidence, or a very short ray): only the depth is redone in double precision
                 h.refined = true;
                 t = (float)exact_tri_depth(S.cold->tri64 + 9 * (size_t)(gprim - S.n_spheres), o64, d64);
                 thi = t * (1.0f + 2.0f * kU);
@@ -675,24 +697,24 @@ RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, cons
                 if (!e.hit) { limit = kInf; gprim = -1; }   // cannot happen for a certain winner; stay safe
             }
         }
-    }
-    if (second) {
-        h.how = 2;
-        Resolve R;
-        R.S = &S; R.o = o64; R.d = d64; R.origin = r.origin; R.skip = skip; R.limit = limit;
-        R.t = e.t; R.gprim = gprim; R.order = gprim >= 0 ? scene_order(S, gprim) : 0;
-        search_all<TRI, HAS_SPH>(S, r, o64, d64, R, bc);
-        if (R.gprim != gprim) {   // someone else won: its position and normal (same arithmetic, same depth)
-            gprim = R.gprim;
-            e = exact_single(S, gprim, o64, d64, r.origin);
+        if (second) {
+            h.how = 2;
+            Resolve R;
+            R.S = &S; R.o = o64; R.d = d64; R.origin = r.origin; R.skip = skip; R.limit = limit;
+            R.t = e.t; R.gprim = gprim; R.order = gprim >= 0 ? scene_order(S, gprim) : 0;
+            search_all<TRI, HAS_SPH>(S, r, o64, d64, R, bc);
+            if (R.gprim != gprim) {   // someone else won: its position and normal (same arithmetic, same depth)
+                gprim = R.gprim;
+                e = exact_single(S, gprim, o64, d64, r.origin);
+            }
+            if (gprim < 0) e.hit = false;
         }
-        if (gprim < 0) e.hit = false;
+        if (scan) {   // upstream's Scene.intersect, literally, in double precision
+            h.how = 2;
+            exact_scan_pass(S, o64, d64, r.origin, e, gprim);
+        }
+        h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
     }
-    if (scan) {   // upstream's Scene.intersect, literally, in double precision
-        h.how = 2;
-        exact_scan_pass(S, o64, d64, r.origin, e, gprim);
-    }
-    h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
     if (e64) *e64 = e;
     if (gprim < 0) return h;
     h.gprim = gprim;
