@@ -625,15 +625,7 @@ RT_DEV void hit_begin(const DevScene &S, const Ray &r, const RayResidue rr, type
 // Everything after the first pass: judge the winner, settle what float32 could not, build the hit
 // record.  `e64`, when given, receives the double-precision record whenever the exact code produced
 // the hit (e64->hit says whether it did).
-//
-// LEAN = true compiles NO settling code: when the winner needs double precision (or a contender,
-// or the ray itself does), the record comes back with how = kHowUnsettled and nothing else valid.
-// The render path uses this for its first pass over the paths and re-traces the few unsettled ones
-// with the full code - the double-precision code runs for ~0.2 % of the rays, but inlined into the
-// hot kernel its registers cost every ray ~20 %.
-constexpr int kHowUnsettled = 3;
-
-template <int TRI, bool HAS_SPH, bool STRICT, bool LEAN = false>
+template <int TRI, bool HAS_SPH, bool STRICT>
 RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
                       BvhCounters bc, ExactHit *e64) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
@@ -666,9 +658,7 @@ RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, cons
     }
     const bool settle = route != kRouteFilter || (gprim >= 0 && (status != 0 || (has_second && !(second_lo > thi))));
     ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
-    if (LEAN) {
-        if (settle) { h.how = kHowUnsettled; return h; }
-    } else if (settle) {
+    if (settle) {
         const Ray64 x64 = ray64(r, rr);
         const D3 o64 = x64.o, d64 = x64.d;
         const bool scan = route == kRouteScan;
