@@ -7,10 +7,12 @@
 // positive floats order like their bit patterns, so one v_min_u32 keeps the best candidate and
 // one v_med3_u32 the runner-up.  After the loops the winner is re-evaluated with per-lane loads:
 //   * certainly hit, certainly alone in front, precise enough  -> accepted as is (float32);
-//   * anything else -> that primitive (or, for a possible tie / a rejected winner, the whole
-//     scene) is re-evaluated by the double-precision code in rt_exact.h.
+//   * anything else -> that primitive is re-evaluated by the double-precision code in rt_exact.h;
+//     for a possible tie or a rejected winner the tables are walked a second time and every
+//     candidate that could still win is evaluated in double precision (`Resolve`).
 // So hit identity never depends on float32 rounding; float32 only decides how often the slow
-// path runs.
+// path runs.  (Scenes too large for ids to fit beside a depth in 32 bits keep best / runner-up as
+// separate registers instead of keys: `PairBest`.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
