@@ -366,3 +366,43 @@ def test_parallelogram_rows_equal_triangle_rows(backend, monkeypatch):
             monkeypatch.delenv("RAYTRACING_AMD_NO_QUADS")
     differing = (np.abs(imgs[0] - imgs[1]).max(axis=2) > 1e-4 * 4).mean()
     assert differing < 5e-3, differing
+
+
+@pytest.mark.parametrize("scale,shift", [(1000.0, (0.0, 0.0, 0.0)), (1e-3, (0.0, 0.0, 0.0)), (1.0, (5000.0, -3000.0, 8000.0)),
+                                         (37.5, (-250.0, 125.0, 60.0))])
+def test_scaled_and_shifted_scenes(backend, scale, shift):
+    """The float32 bounds are relative to the scene's size and position, upstream's `|det| < 1e-6`
+    and `depth > 1e-10` cuts are absolute: the room scaled by 1000 and by 1/1000 (where most
+    triangles fall below the determinant cut and can never be hit) and moved far from the origin
+    (float32 coordinates lose 3-4 digits there) must still return upstream's hits exactly."""
+    import dataclasses
+
+    base = h.packed_scene("room_horse")
+    T = np.asarray(shift)
+    tv = (base.tri_verts.reshape(-1, 3) * scale + T).reshape(-1, 9)
+    sph = base.spheres.copy()
+    sph[:, :3] = sph[:, :3] * scale + T
+    sph[:, 3] *= scale
+    aabb = base.mesh_aabb.copy()
+    aabb[:, :3] = aabb[:, :3] * scale + T
+    aabb[:, 3:] = aabb[:, 3:] * scale + T
+    cam = tuple(np.asarray(base.cam_pos) * scale + T)
+    sc = dataclasses.replace(base, tri_verts=np.ascontiguousarray(tv), spheres=sph, mesh_aabb=aabb, cam_pos=cam)
+    backend.set_scene(sc)
+    rng = np.random.default_rng(int(scale * 7) % 1000 + 1)
+    n = 20000
+    o = ((rng.uniform(-1.1, 1.1, (n, 3))) * scale + T).astype(np.float32).astype(np.float64)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    want = h.oracle_intersect(sc, o, d)
+    got = backend.intersect(o, d)
+    assert np.array_equal(got["obj"], want["obj"]) and np.array_equal(got["prim"], want["prim"])
+    hit = want["obj"] >= 0
+    assert hit.mean() > (0.05 if scale < 1 else 0.5)
+    rel = np.abs(got["t"][hit] - want["t"][hit]) / want["t"][hit]
+    assert rel.max() <= TOL, rel.max()
+    # and a short render of the transformed scene runs through the same tables without trouble
+    backend.resize(64, 36)
+    backend.render(64, 36, 0, 2, 4, 9)
+    backend.synchronize()
+    assert np.isfinite(backend.read()).all()
