@@ -406,3 +406,74 @@ def test_scaled_and_shifted_scenes(backend, scale, shift):
     backend.render(64, 36, 0, 2, 4, 9)
     backend.synchronize()
     assert np.isfinite(backend.read()).all()
+
+
+def test_ties_and_degenerate_geometry(backend):
+    """Exact ties and degenerate primitives, where upstream's answer is decided by list order
+    (stable sort by depth: scene.py:24-27; first minimum inside a mesh: mesh.py:101-110):
+    coincident triangles in two meshes, coincident spheres, a fan of triangles sharing an apex hit
+    dead-on, needle and zero-area triangles, rays starting inside a sphere and on a sphere's surface,
+    a sphere tangent to a plane."""
+    import dataclasses
+
+    base = h.packed_scene("room")
+    quad = [(-0.5, -0.5, 0.25), (0.5, -0.5, 0.25), (0.5, 0.5, 0.25), (-0.5, 0.5, 0.25)]
+    q = np.array(quad)
+    mesh_a = np.array([np.concatenate([q[0], q[1], q[2]]), np.concatenate([q[0], q[2], q[3]])])
+    mesh_b = mesh_a.copy()                                   # coincident with mesh_a, later in the object list
+    apex = np.array([0.0, 0.0, -0.25])
+    ring = [np.array([0.4 * np.cos(a), 0.4 * np.sin(a), -0.5]) for a in np.linspace(0, 2 * np.pi, 7)[:-1]]
+    fan = np.array([np.concatenate([apex, ring[i], ring[(i + 1) % 6]]) for i in range(6)])
+    junk = np.array([np.concatenate([(0.9, 0.9, 0.9), (0.9, 0.9, 0.9), (0.9, 0.9, 0.9)]),            # a point
+                     np.concatenate([(-0.9, 0.0, 0.0), (0.9, 1e-9, 0.0), (0.0, 5e-10, 0.0)]),       # a needle below the det cut
+                     np.concatenate([(0.2, -0.9, -0.9), (0.2, 0.9, -0.9), (0.2, 0.0, 0.9)])])        # an ordinary one
+    new_meshes = [mesh_a, mesh_b, fan, junk]
+    tv = np.concatenate([base.tri_verts] + new_meshes)
+    begin = list(base.mesh_tri_begin)
+    for m in new_meshes:
+        begin.append(begin[-1] + len(m))
+    aabb = [base.mesh_aabb]
+    for m in new_meshes:
+        pts = m.reshape(-1, 3)
+        aabb.append(np.concatenate([pts.min(0), pts.max(0)])[None])
+    n_obj0 = base.n_objects
+    spheres = np.concatenate([base.spheres, [[0.3, 0.3, -0.3, 0.2], [0.3, 0.3, -0.3, 0.2], [-0.6, -0.8, 0.0, 0.2]]])   # two coincident; one tangent to the floor y = -1
+    kinds = np.concatenate([base.obj_kind, [1, 1, 1, 1, 0, 0, 0]]).astype(np.int32)
+    index = np.concatenate([base.obj_index, [base.n_meshes + k for k in range(4)] + [base.n_spheres + k for k in range(3)]]).astype(np.int32)
+    mats = np.concatenate([base.materials, np.tile(base.materials[:1], (7, 1))])
+    sc = dataclasses.replace(
+        base, obj_kind=kinds, obj_index=index, materials=np.ascontiguousarray(mats), spheres=np.ascontiguousarray(spheres),
+        sphere_obj=np.concatenate([base.sphere_obj, [n_obj0 + 4, n_obj0 + 5, n_obj0 + 6]]).astype(np.int32),
+        mesh_aabb=np.ascontiguousarray(np.concatenate(aabb)), mesh_obj=np.concatenate([base.mesh_obj, [n_obj0 + k for k in range(4)]]).astype(np.int32),
+        mesh_tri_begin=np.asarray(begin, np.int32), tri_verts=np.ascontiguousarray(tv), object_names=base.object_names + ["x"] * 7)
+    backend.set_scene(sc)
+    rng = np.random.default_rng(17)
+    o, d = [], []
+    for _ in range(4000):                                   # at the coincident quads, from both sides
+        p = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), 0.25]); s = np.array([rng.uniform(-0.9, 0.9), rng.uniform(-0.9, 0.9), rng.choice([-0.9, 0.9])])
+        o.append(s); d.append(p - s)
+    for _ in range(2000):                                   # dead-on at the fan's apex and along its spokes
+        s = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 0.9])
+        k = rng.integers(0, 6); f = rng.choice([0.0, 0.25, 0.5, 1.0])
+        o.append(s); d.append(apex * (1 - f) + ring[k] * f - s)
+    for _ in range(3000):                                   # from inside / on the surface of the coincident spheres, and at the tangent point
+        c = np.array([0.3, 0.3, -0.3]); u = rng.normal(size=3); u /= np.linalg.norm(u)
+        o.append(c + u * rng.choice([0.0, 0.1, 0.2])); d.append(rng.normal(size=3))
+        o.append(np.array([rng.uniform(-0.9, 0.9), rng.uniform(-0.5, 0.9), rng.uniform(-0.9, 0.9)])); d.append(np.array([-0.6, -1.0, 0.0]) - o[-1])
+    for _ in range(5000):
+        o.append(rng.uniform(-0.95, 0.95, 3)); d.append(rng.normal(size=3))
+    o = np.array(o).astype(np.float32).astype(np.float64)
+    d = np.array(d); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    want = h.oracle_intersect(sc, o, d)
+    got = backend.intersect(o, d)
+    _check_hits(got, want)
+    assert (want["obj"] == n_obj0).sum() > 1000 and (want["obj"] == n_obj0 + 1).sum() == 0     # the first of the coincident meshes always wins
+    assert (want["obj"] == n_obj0 + 5).sum() == 0                                              # and the first of the coincident spheres
+    # the same rays as bounce rays leaving whatever they would hit first: origin rule on both sides
+    first = want
+    o2 = first["pos"][first["obj"] >= 0].astype(np.float32).astype(np.float64)
+    g2 = first["gprim"][first["obj"] >= 0].astype(np.int32)
+    d2 = rng.normal(size=o2.shape); d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    with h.origin_rule():
+        want2 = h.oracle_intersect(sc, o2, d2, origin_prim=g2)
+    _check_hits(backend.intersect(o2, d2, origin_prim=g2), want2)
