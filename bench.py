@@ -176,7 +176,7 @@ def main() -> None:
         flops_launch = algorithmic_flops(st) / launches
         achieved = flops_launch / kernel_s / 1e12
         out = {
-            "metric": "rays/sec, room.py 1080p 256 spp 8 bounces",
+            "metric": "rays/sec at 1/2/4/8 MI355X, room.py 1080p; % of FP32 VALU peak",
             "value": rays_all / dt_all,
             "unit": "rays/s",
             "n_gpus": world,

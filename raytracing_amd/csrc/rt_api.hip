@@ -455,13 +455,17 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
     HIP_TRY(c, c->mesh_tri_begin.upload(mtb)); HIP_TRY(c, c->obj_kind.upload(okind)); HIP_TRY(c, c->obj_index.upload(oindex));
     if (has_sky) HIP_TRY(c, c->sky.upload(sky));
+    int32_t n_top_nodes = 0;
     if (use_bvh) {
-        // eight threadings of the one hierarchy, one per octant of ray directions (front-to-back order)
-        std::vector<rt_bvh_node> all, one;
-        all.reserve(8 * bvh_nodes.size());
+        // Device form: eight threadings of the one hierarchy, one per octant of ray directions (children
+        // nearer along the ray first), each laid out top levels first - the kernels stage those in LDS -
+        // and depth-first below.
+        std::vector<rt_bvh_node> all, one, dev;
+        all.reserve(8 * bvh_nodes.size() + 1);
         for (int oct = 0; oct < 8; ++oct) {
             bvh::rethread(bvh_nodes, oct, one);
-            all.insert(all.end(), one.begin(), one.end());
+            n_top_nodes = bvh::reorder_top_first(one, kTopNodes, dev);   // level sizes, hence the count, are the same for every octant
+            all.insert(all.end(), dev.begin(), dev.end());
         }
         HIP_TRY(c, c->bvh.upload(all));
     }
@@ -477,6 +481,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.materials = c->materials.as<MatRow>();
     S.leaf_rows = c->leaf_rows.as<TriRow>();
     S.bvh_nodes = use_bvh ? c->bvh.as<BvhNode>() : nullptr; S.n_bvh_nodes = use_bvh ? (int32_t)bvh_nodes.size() : 0;
+    S.n_top_nodes = std::getenv("RAYTRACING_AMD_NO_LDS_TOP") ? 0 : n_top_nodes;   // switch for A/B runs
     ColdScene cold{};
     cold.tri64 = c->tri64.as<double>(); cold.sph64 = c->sph64.as<double>(); cold.aabb64 = c->aabb64.as<double>();
     cold.mesh_tri_begin = c->mesh_tri_begin.as<int32_t>(); cold.obj_kind = c->obj_kind.as<int32_t>(); cold.obj_index = c->obj_index.as<int32_t>();

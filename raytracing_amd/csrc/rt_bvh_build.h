@@ -189,6 +189,49 @@ inline void rethread(const std::vector<rt_bvh_node> &src, int octant, std::vecto
     for (auto &nd : dst) if (nd.skip >= n) nd.skip = -1;
 }
 
+// Device order of a valid threaded hierarchy: the nodes of the top levels first (breadth-first:
+// these are the ones every ray visits, and the kernels stage them in LDS), then everything below in
+// the original depth-first order.  A top node can no longer find its first child at index + 1, so an
+// inner node's tri_begin_count carries it explicitly as -(child + 2); -1 still means "the next node"
+// (true for every node below the top, whose children moved with it).  Leaves are unchanged.
+// Returns the number of top nodes (<= max_top; whole levels only).
+inline int32_t reorder_top_first(const std::vector<rt_bvh_node> &src, int32_t max_top, std::vector<rt_bvh_node> &dst) {
+    const int32_t n = (int32_t)src.size();
+    dst.clear();
+    if (n == 0) return 0;
+    std::vector<int32_t> depth(n, 0);
+    {   // depth of every node from the nesting of the skip links
+        std::vector<int32_t> open_end;
+        for (int32_t i = 0; i < n; ++i) {
+            while (!open_end.empty() && open_end.back() <= i) open_end.pop_back();
+            depth[i] = (int32_t)open_end.size();
+            if (src[i].tri_begin_count < 0) open_end.push_back(src[i].skip < 0 ? n : src[i].skip);
+        }
+    }
+    int32_t max_depth = 0;
+    for (int32_t d : depth) max_depth = std::max(max_depth, d);
+    std::vector<int32_t> per_level(max_depth + 2, 0);
+    for (int32_t d : depth) per_level[d]++;
+    int32_t levels = 0, n_top = 0;                    // whole levels while they fit
+    while (levels <= max_depth && n_top + per_level[levels] <= max_top) { n_top += per_level[levels]; ++levels; }
+    std::vector<int32_t> where(n, -1);
+    int32_t next = 0;
+    for (int32_t lv = 0; lv < levels; ++lv)
+        for (int32_t i = 0; i < n; ++i) if (depth[i] == lv) where[i] = next++;
+    for (int32_t i = 0; i < n; ++i) if (where[i] < 0) where[i] = next++;
+    dst.resize(n);
+    for (int32_t i = 0; i < n; ++i) {
+        rt_bvh_node nd = src[i];
+        nd.skip = src[i].skip < 0 ? -1 : where[src[i].skip];
+        if (src[i].tri_begin_count < 0) {
+            const int32_t child = where[i + 1];
+            nd.tri_begin_count = (child == where[i] + 1) ? -1 : -(child + 2);
+        }
+        dst[where[i]] = nd;
+    }
+    return n_top;
+}
+
 // Structural and containment checks.  Returns an empty string when the hierarchy is safe to use:
 // links only point forward and nest, leaves index [0, n_tris) and cover every triangle exactly once,
 // every leaf box contains its triangles and every box lies inside its parent's.

@@ -360,7 +360,16 @@ RT_DEV TriRow load_tri_row_lane(const TriRow *rows, int i) {
 // then never drop a box the exact ray touches.  A NaN slab value (0 x inf: origin exactly on a box plane, direction component zero) drops out of
 // min/max and leaves that slab unconstrained.  A box is skipped when the ray misses it or enters it
 // beyond the sink's bound.
-struct BvhCounters { uint32_t nodes, tris; };
+typedef const f4 __attribute__((address_space(3))) *lds_f4_ptr;
+
+// Per-query walk context: test counters, and where the top levels of the hierarchy sit in LDS (if the
+// kernel staged them: n_top = 0 reads every node from memory).
+struct BvhCounters {
+    uint32_t nodes, tris;
+    lds_f4_ptr top; int32_t n_top;
+};
+
+RT_DEV BvhCounters bvh_counters() { BvhCounters b; b.nodes = 0; b.tris = 0; b.top = nullptr; b.n_top = 0; return b; }
 
 //
 // The walk is resumable: it starts at `node` (0 = root), visits at most `budget` boxes before
@@ -376,6 +385,7 @@ RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters 
     // the threading for this ray's octant: children nearer along the ray come first
     const int oct = (r.dx < 0.0f ? 1 : 0) | (r.dy < 0.0f ? 2 : 0) | (r.dz < 0.0f ? 4 : 0);
     const f4 *nodes = (const f4 *)(S.bvh_nodes + (size_t)oct * (size_t)S.n_bvh_nodes);
+    const lds_f4_ptr top = bc.top + 2 * kTopNodes * oct;
     const TriRow *rows = S.leaf_rows;
     if (S.n_bvh_nodes <= 0) node = -1;
     int visited = 0;
@@ -386,7 +396,9 @@ RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters 
         int32_t leaf = -1;
         while (node >= 0 && visited < budget) {
             ++visited;
-            const f4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
+            f4 a, b;
+            if (node < bc.n_top) { a = top[2 * node]; b = top[2 * node + 1]; }                // top levels: LDS
+            else { a = nodes[2 * (size_t)node]; b = nodes[2 * (size_t)node + 1]; }
             const float skip_bits = a.w, leaf_bits = b.w;
             const int32_t skip = (int32_t)f2u(skip_bits), info = (int32_t)f2u(leaf_bits);
             const float x0 = (a.x - oxp) * ix, x1 = (b.x - oxm) * ix;
@@ -397,7 +409,7 @@ RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters 
             bc.nodes++;
             const bool hit = tn <= tf;
             if (hit && info >= 0) { leaf = info; node = skip; break; }
-            node = hit ? node + 1 : skip;
+            node = hit ? (info == -1 ? node + 1 : -info - 2) : skip;   // inner node: first child, given or next
         }
         if (leaf < 0) break;
         const int first = leaf >> 4, cnt = leaf & 15;
@@ -742,7 +754,7 @@ template <int TRI, bool HAS_SPH, bool STRICT>
 RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, ExactHit *e64, const RayResidue rr) {
     typename FirstPass<TRI>::type first;
     first.init(S);
-    BvhCounters bc; bc.nodes = 0; bc.tris = 0;
+    BvhCounters bc = bvh_counters();
     if (ray_route<TRI>(r) == kRouteFilter) {
         hit_begin<TRI, HAS_SPH>(S, r, rr, first);
         if (TRI == kTriBvh) { int node = 0; search_bvh(S, r, first, bc, node, 0x7FFFFFFF); }

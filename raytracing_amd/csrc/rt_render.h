@@ -287,7 +287,18 @@ __global__ __launch_bounds__(256, TRI == kTriBvh ? 3 : 4) void k_render(const De
     // Statistics are kept per WAVE in scalar registers (lane counts of ballots taken where the wave
     // is converged), not per lane: six vector registers less for the whole life of the kernel.
     uint32_t w_rays = 0, w_paths = 0, w_exact = 0, w_refine = 0, w_sky = 0, w_shaded = 0;
-    BvhCounters bc; bc.nodes = 0; bc.tris = 0;   // hierarchy only: per-lane sums, reduced at the end
+    // hierarchy scenes: the workgroup stages the top levels of the hierarchy in LDS once (every ray
+    // visits them; an LDS read costs a fraction of even an L1 hit and takes no vector-memory slot)
+    __shared__ f4 top_nodes[TRI == kTriBvh ? 8 * 2 * kTopNodes : 2];
+    BvhCounters bc = bvh_counters();   // hierarchy only: per-lane test counts, reduced at the end
+    if (TRI == kTriBvh) {
+        for (int oct = 0; oct < 8; ++oct) {
+            const f4 *src = (const f4 *)(S.bvh_nodes + (size_t)oct * (size_t)S.n_bvh_nodes);
+            for (int i = threadIdx.x; i < 2 * S.n_top_nodes; i += 256) top_nodes[2 * kTopNodes * oct + i] = src[i];
+        }
+        __syncthreads();
+        bc.top = (lds_f4_ptr)top_nodes; bc.n_top = S.n_top_nodes;
+    }
     // hierarchy only: a closest-hit query in progress (walked a slice per trip of the main loop)
     typename FirstPass<TRI>::type first;
     first.init(S);
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(256, TRI == kTriBvh ? 3 : 4) void k_render(const De
                 if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, kWalkSlice);
                 if (walk_node < 0) {
                     walking = false;
-                    BvhCounters second_pass; second_pass.nodes = 0; second_pass.tris = 0;
+                    BvhCounters second_pass = bc; second_pass.nodes = 0; second_pass.tris = 0;
                     h = hit_finish<TRI, HAS_SPH, false>(S, ray, rr, first, second_pass, nullptr);
                     bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
                     alive = path_shade(S, p, A.max_bounces, h, er, eg, eb);

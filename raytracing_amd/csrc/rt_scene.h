@@ -12,6 +12,7 @@
 namespace rt {
 
 constexpr float kU = 5.9604644775390625e-08f;  // 2^-24, unit roundoff of binary32
+constexpr int kTopNodes = 128;                 // hierarchy nodes per ray octant a workgroup keeps in LDS (8 x 128 x 32 B = 32 KB)
 
 // One live triangle, 16 dwords = one s_load_dwordx16.
 // t = -(N.o + kN) / (N.d);  p = o + t d;  u = e1.p + k1;  v = e2.p + k2;  w = 1 - u - v
@@ -83,8 +84,9 @@ struct DevScene {
     const MatRow *materials;                          // [n_objects]
     const ColdScene *cold;                            // device memory
     const TriRow *leaf_rows;                          // hierarchy: triangle rows in leaf order
-    const BvhNode *bvh_nodes; int32_t n_bvh_nodes;    // threaded hierarchy over tri_rows (then in leaf order), 8 copies of
-                                                      // n_bvh_nodes nodes, one per ray-direction octant; 0 = none
+    const BvhNode *bvh_nodes; int32_t n_bvh_nodes;    // threaded hierarchy over leaf_rows: 8 copies of n_bvh_nodes nodes, one per
+                                                      // ray-direction octant, each with its top levels first; 0 = none
+    int32_t n_top_nodes;                              // per copy, the first n_top_nodes nodes are the top levels (staged in LDS)
     int32_t n_spheres;
     float scene_radius;       // bound on the distance from the world origin of every vertex, small-sphere point and the camera
     uint32_t key_mask;        // low bits of a hit key that hold the primitive id

@@ -100,7 +100,18 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S, const Wf
     typename FirstPass<TRI>::type first;
     first.init(S);
     int walk_node = -1;
-    BvhCounters bc; bc.nodes = 0; bc.tris = 0;
+    // hierarchy scenes: the workgroup stages the top levels of the hierarchy in LDS once (every ray
+    // visits them; an LDS read costs a fraction of even an L1 hit and takes no vector-memory slot)
+    __shared__ f4 top_nodes[8 * 2 * kTopNodes];
+    BvhCounters bc = bvh_counters();   // hierarchy only: per-lane test counts, reduced at the end
+    if (TRI == kTriBvh) {
+        for (int oct = 0; oct < 8; ++oct) {
+            const f4 *src = (const f4 *)(S.bvh_nodes + (size_t)oct * (size_t)S.n_bvh_nodes);
+            for (int i = threadIdx.x; i < 2 * S.n_top_nodes; i += 256) top_nodes[2 * kTopNodes * oct + i] = src[i];
+        }
+        __syncthreads();
+        bc.top = (lds_f4_ptr)top_nodes; bc.n_top = S.n_top_nodes;
+    }
     for (;;) {
         // ---- idle lanes take the next rays of the queue -------------------------------------------
         unsigned long long idle = __ballot(!have);
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S, const Wf
             }
             if (walk_node >= 0) search_bvh(S, r, first, bc, walk_node, kWfSlice);
             if (walk_node < 0) {
-                BvhCounters second_pass; second_pass.nodes = 0; second_pass.tris = 0;
+                BvhCounters second_pass = bc; second_pass.nodes = 0; second_pass.tris = 0;
                 const Hit h = hit_finish<TRI, HAS_SPH, false>(S, r, rr, first, second_pass, nullptr);
                 bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
                 WfHit w;
