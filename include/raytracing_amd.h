@@ -167,6 +167,17 @@ int rt_intersect_batch(rt_ctx *ctx, int64_t n, const double *org, const double *
                        const int32_t *origin_prim, int32_t *obj, int32_t *prim, int32_t *gprim,
                        int32_t *how, double *t, double *normal, double *pos);
 
+/* Renderer.raytrace(ray, depth=first_depth) (renderer.py:21-79) for n caller-supplied rays: the
+ * radiance carried back along the path that starts with each ray, i.e. upstream's return value for
+ * incoming_light = 0 and ray_color = 1.  Host arrays; org / dir are doubles as the Python objects
+ * hold them and are rounded to float32, which is then the ray that is traced.  inside (may be NULL
+ * = all false) is Ray.inside (ray.py:10).  first_depth > max_bounces yields 0 (renderer.py:29-30).
+ * Ray i draws its random numbers from the stream of (pixel = stream_begin + i, sample) under `seed`,
+ * the same keying rt_render uses, segment counter = depth + 1. */
+int rt_raytrace_batch(rt_ctx *ctx, int64_t n, const double *org, const double *dir, const uint8_t *inside,
+                      int32_t first_depth, int32_t max_bounces, uint64_t seed, uint32_t sample,
+                      uint32_t stream_begin, float *rgb);
+
 /* Accumulation buffer: RenderResult.arr (render_result.py:14,24-27).  The context owns one
  * float32 (W,H,3) device buffer, (re)allocated by rt_accum_resize and zeroed. */
 int rt_accum_resize(rt_ctx *ctx, int32_t width, int32_t height);

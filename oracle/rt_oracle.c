@@ -369,14 +369,13 @@ typedef struct {
     double *org, *dir; int32_t *inside, *obj, *prim; double *t; int n;
 } seg_trace;
 
-static v3 trace_path(const rt_scene_desc *s, v3 o, v3 d, int max_bounces, draw_stream *rng,
-                     uint64_t *rays, seg_trace *tr) {
+static v3 trace_path_from(const rt_scene_desc *s, v3 o, v3 d, int inside, int first_depth, int max_bounces,
+                          draw_stream *rng, uint64_t *rays, seg_trace *tr) {
     v3 colors[64];
     int n_colors = 0;
-    int inside = 0;
     int origin = -1;
     v3 terminal = V(0, 0, 0);
-    for (int depth = 0;; ++depth) {
+    for (int depth = first_depth;; ++depth) {
         if (depth > max_bounces) { terminal = V(0, 0, 0); break; } /* renderer.py:29-30 */
         hit_rec h;
         (*rays)++;
@@ -424,6 +423,25 @@ static v3 trace_path(const rt_scene_desc *s, v3 o, v3 d, int max_bounces, draw_s
     v3 L = terminal;
     for (int i = n_colors - 1; i >= 0; --i) L = vprod(colors[i], L); /* renderer.py:78 */
     return L;
+}
+
+static v3 trace_path(const rt_scene_desc *s, v3 o, v3 d, int max_bounces, draw_stream *rng,
+                     uint64_t *rays, seg_trace *tr) {
+    return trace_path_from(s, o, d, 0, 0, max_bounces, rng, rays, tr);
+}
+
+/* Renderer.raytrace(ray, depth=first_depth) (renderer.py:21-79) for n given rays; ray i draws from
+ * the stream of (pixel = stream_begin + i, sample). */
+void orc_raytrace_batch(const rt_scene_desc *s, int64_t n, const double *org, const double *dir,
+                        const uint8_t *inside, int first_depth, int max_bounces, uint64_t seed,
+                        uint32_t sample, uint32_t stream_begin, double *rgb) {
+    for (int64_t i = 0; i < n; ++i) {
+        draw_stream rng = {stream_begin + (uint32_t)i, sample, seed, 0, 0, 0, NULL, 0};
+        uint64_t r = 0;
+        v3 L = trace_path_from(s, V(org[3 * i], org[3 * i + 1], org[3 * i + 2]), V(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]),
+                               inside ? inside[i] != 0 : 0, first_depth, max_bounces, &rng, &r, NULL);
+        rgb[3 * i] = L.x; rgb[3 * i + 1] = L.y; rgb[3 * i + 2] = L.z;
+    }
 }
 
 /* One path of pixel (x, y), sample index `sample`; optionally records its segments. */

@@ -24,7 +24,7 @@ RT_ERR_STOPPED = 5
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
            "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms",
-           "rt_debug_trace_paths", "rt_build_bvh", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
+           "rt_debug_trace_paths", "rt_raytrace_batch", "rt_build_bvh", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
 
 class RtRenderParams(C.Structure):
@@ -85,6 +85,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_debug_uniforms.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int32, fp]
     lib.rt_debug_trace_paths.argtypes = [vp, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                          fp, ip, ip, ip, ip, fp, fp, fp]
+    lib.rt_raytrace_batch.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_uint64,
+                                      C.c_uint32, C.c_uint32, fp]
     lib.rt_build_bvh.argtypes = [C.c_int32, dp, C.c_int32, vp, C.c_int32, ip, ip]
     lp = C.POINTER(C.c_int64)
     lib.rt_obj_open.argtypes = [C.c_char_p, C.POINTER(vp), ip, lp, lp]
@@ -198,6 +200,27 @@ class HipBackend:
     def debug_uniforms(self, pixel: int, sample: int, seed: int, n_segments: int) -> np.ndarray:
         out = np.empty((n_segments, 5), dtype=np.float32)
         self._check(self.lib.rt_debug_uniforms(self.handle, pixel, sample, seed, n_segments,
+                                               out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def raytrace(self, origins, directions, max_bounces: int, seed: int = 0, inside=None, first_depth: int = 0,
+                 sample: int = 0, stream_begin: int = 0) -> np.ndarray:
+        """Radiance of the paths that start with the given rays (upstream's ``Renderer.raytrace``)."""
+        org = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        drs = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+        n = org.shape[0]
+        if drs.shape[0] != n:
+            raise ValueError("origins and directions differ in length")
+        ins = None
+        if inside is not None:
+            ins_arr = np.ascontiguousarray(inside, dtype=np.uint8).reshape(-1)
+            if ins_arr.shape[0] != n:
+                raise ValueError("inside flags and rays differ in length")
+            ins = ins_arr.ctypes.data_as(C.POINTER(C.c_uint8))
+        out = np.empty((n, 3), dtype=np.float32)
+        dp = C.POINTER(C.c_double)
+        self._check(self.lib.rt_raytrace_batch(self.handle, n, org.ctypes.data_as(dp), drs.ctypes.data_as(dp), ins,
+                                               first_depth, max_bounces, seed & 0xFFFFFFFFFFFFFFFF, sample, stream_begin,
                                                out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 

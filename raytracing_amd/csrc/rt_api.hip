@@ -938,3 +938,38 @@ extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *x
     HIP_TRY(c, hipMemcpy(seg_org, b_org.p, ns * 12, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(seg_dir, b_dir.p, ns * 12, hipMemcpyDeviceToHost));
     return RT_OK;
 }
+
+// Renderer.raytrace for a batch of caller-supplied rays (see k_raytrace).
+extern "C" int rt_raytrace_batch(rt_ctx *c, int64_t n, const double *org, const double *dir, const uint8_t *inside,
+                                 int32_t first_depth, int32_t max_bounces, uint64_t seed, uint32_t sample,
+                                 uint32_t stream_begin, float *rgb) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (n < 0 || (n > 0 && (!org || !dir || !rgb)) || first_depth < 0 || max_bounces < 0 || max_bounces > 62)
+        return fail(c, RT_ERR_INVALID_ARG, "rt_raytrace_batch: bad arguments");
+    if (n > (1ll << 31)) return fail(c, RT_ERR_INVALID_ARG, "rt_raytrace_batch: at most 2^31 rays per call");
+    if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "rt_raytrace_batch: no scene set");
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf b_org, b_dir, b_inside, b_rgb;
+    const size_t n3 = 3 * (size_t)n * sizeof(double);
+    HIP_TRY(c, b_org.ensure(n3)); HIP_TRY(c, b_dir.ensure(n3)); HIP_TRY(c, b_rgb.ensure(3 * (size_t)n * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(b_org.p, org, n3, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(b_dir.p, dir, n3, hipMemcpyHostToDevice));
+    if (inside) {
+        HIP_TRY(c, b_inside.ensure((size_t)n));
+        HIP_TRY(c, hipMemcpy(b_inside.p, inside, (size_t)n, hipMemcpyHostToDevice));
+    }
+    RaytraceArgs A{};
+    A.n = n; A.org = b_org.as<double>(); A.dir = b_dir.as<double>(); A.inside = inside ? b_inside.as<uint8_t>() : nullptr;
+    A.first_depth = first_depth; A.max_bounces = max_bounces;
+    A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32); A.sample = sample; A.stream_begin = stream_begin;
+    A.rgb = b_rgb.as<float>(); A.stats = c->stats.as<unsigned long long>();
+    const DevScene S = c->S;
+    dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
+        hipLaunchKernelGGL((k_raytrace<decltype(T)::value, decltype(P)::value>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, S, A);
+    });
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(rgb, b_rgb.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}

@@ -470,4 +470,53 @@ __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S, const Tra
     A.rgb[3 * i] = p.tr * er; A.rgb[3 * i + 1] = p.tg * eg; A.rgb[3 * i + 2] = p.tb * eb;
 }
 
+// Renderer.raytrace (renderer.py:21-79) for caller-supplied rays: one thread follows one path from
+// its given first ray (origin, direction, Ray.inside, upstream's `depth` argument) to its end and
+// writes the radiance.  The float32 rounding of the given ray is the ray that is traced.
+struct RaytraceArgs {
+    long long n;
+    const double *org, *dir;     // [n][3]
+    const uint8_t *inside;       // [n] or null
+    int32_t first_depth, max_bounces;
+    uint32_t seed_lo, seed_hi, sample;
+    uint32_t stream_begin;       // ray i draws from the random stream of "pixel" stream_begin + i
+    float *rgb;                  // [n][3]
+    unsigned long long *stats;
+};
+
+template <int TRI, bool HAS_SPH>
+__global__ __launch_bounds__(256) void k_raytrace(const DevScene S, const RaytraceArgs A) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long rays = 0, sky = 0, shaded = 0, paths = 0;
+    if (i < A.n) {
+        Path p;
+        p.pixel = A.stream_begin + (uint32_t)i;
+        p.key0 = p.pixel ^ A.seed_lo; p.key1 = A.sample ^ A.seed_hi;
+        p.ox = (float)A.org[3 * i]; p.oy = (float)A.org[3 * i + 1]; p.oz = (float)A.org[3 * i + 2];
+        p.dx = (float)A.dir[3 * i]; p.dy = (float)A.dir[3 * i + 1]; p.dz = (float)A.dir[3 * i + 2];
+        p.tr = p.tg = p.tb = 1.0f; p.depth = A.first_depth; p.origin = -1;
+        p.inside = A.inside ? A.inside[i] != 0 : false;
+        float er = 0, eg = 0, eb = 0;
+        paths = 1;
+        if (p.depth <= A.max_bounces) {   // renderer.py:29-30
+            for (;;) {
+                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, false);
+                const Hit h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, no_residue());
+                rays++;
+                if (h.obj < 0) sky++; else shaded++;
+                if (!path_shade(S, p, A.max_bounces, h, er, eg, eb)) break;
+            }
+        }
+        A.rgb[3 * i] = p.tr * er; A.rgb[3 * i + 1] = p.tg * eg; A.rgb[3 * i + 2] = p.tb * eb;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_down(rays, off, 64); sky += __shfl_down(sky, off, 64);
+        shaded += __shfl_down(shaded, off, 64); paths += __shfl_down(paths, off, 64);
+    }
+    if (lane_id() == 0) {
+        atomicAdd(A.stats + kStatRays, rays); atomicAdd(A.stats + kStatPaths, paths);
+        atomicAdd(A.stats + kStatSky, sky); atomicAdd(A.stats + kStatShaded, shaded);
+    }
+}
+
 }  // namespace rt

@@ -277,6 +277,7 @@ class Renderer:
         self.samples_per_launch = samples_per_launch
         self._backend = None
         self._thread: Optional[Thread] = None
+        self._raytrace_calls = 0
 
     # -- set-up ---------------------------------------------------------------------------------
     def init_render(self, render_settings: RenderSettings) -> None:
@@ -363,8 +364,33 @@ class Renderer:
         if self._thread is not None:
             self._thread.join(timeout)
 
-    # -- single ray (diagnostics) ---------------------------------------------------------------
+    # -- single rays / ray batches ---------------------------------------------------------------
+    def _path_backend(self):
+        if self.render_settings is None:
+            raise RuntimeError("Renderer.raytrace needs render_settings (MAX_BOUNCES) and a scene: call init_render first "
+                               "or set .scene and .render_settings")
+        if self._backend is not None:
+            return self._backend
+        scene = self.scene if self.scene is not None else self.render_settings.SCENE
+        return scene._device_scene(self.device)
+
+    def raytrace_batch(self, origins, directions, inside=None, depth: int = 0, sample: Optional[int] = None) -> np.ndarray:
+        """Radiance (n, 3) float32 of the paths that start with the given rays, traced on the GPU:
+        upstream's ``raytrace`` (renderer.py:21-79) for many rays at once.  Every call draws from a
+        fresh random stream unless ``sample`` pins it."""
+        if sample is None:
+            sample, self._raytrace_calls = self._raytrace_calls, self._raytrace_calls + 1
+        return self._path_backend().raytrace(origins, directions, self.render_settings.MAX_BOUNCES, self.seed, inside=inside,
+                                             first_depth=depth, sample=sample)
+
     def raytrace(self, ray: Ray, incoming_light=None, ray_color=None, depth=None):
-        raise NotImplementedError(
-            "per-ray CPU tracing is not part of this backend; use Renderer.render / render_area (GPU), "
-            "or Scene.intersect / Scene.intersect_batch for closest-hit queries")
+        """``incoming_light + ray_color * L(ray)`` as upstream returns it (renderer.py:21-79); the
+        path is traced on the GPU, one ray per call (use ``raytrace_batch`` for many)."""
+        incoming_light = Vec3(0, 0, 0) if incoming_light is None else incoming_light
+        ray_color = Vec3(1, 1, 1) if ray_color is None else ray_color
+        depth = 0 if depth is None else int(depth)
+        if depth > self.render_settings.MAX_BOUNCES:
+            return Vec3(0, 0, 0)
+        L = self.raytrace_batch([tuple(ray.origin)], [tuple(ray.direction)], inside=[bool(getattr(ray, "inside", False))],
+                                depth=depth)[0]
+        return incoming_light + Vec3(*(float(ray_color[k]) * float(L[k]) for k in range(3)))

@@ -54,6 +54,8 @@ def oracle():
                                     _dp, _dp, _ip, _ip, _ip, _dp, _ip]
     lib.orc_render.argtypes = [C.POINTER(RtSceneDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_uint64, _dp, C.POINTER(C.c_uint64), C.c_int]
+    lib.orc_raytrace_batch.argtypes = [C.POINTER(RtSceneDesc), C.c_int64, _dp, _dp, C.POINTER(C.c_uint8), C.c_int, C.c_int,
+                                       C.c_uint64, C.c_uint32, C.c_uint32, _dp]
     lib.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.orc_counters.argtypes = [C.POINTER(C.c_uint64)]
     lib.orc_max_threads.restype = C.c_int
@@ -120,6 +122,20 @@ def oracle_render(scene: PackedScene, W, H, spp, bounces, seed=SEED_RENDER, rect
     d = scene.desc()
     lib.orc_render(C.byref(d), W, H, x0, x1, y0, y1, sample_begin, spp, bounces, seed, _d(arr), C.byref(rays), nthreads)
     return arr, int(rays.value)
+
+
+def oracle_raytrace(scene: PackedScene, org, dirs, bounces, seed=SEED_RENDER, inside=None, first_depth=0, sample=0,
+                    stream_begin=0) -> np.ndarray:
+    """Renderer.raytrace for given rays (oracle side of HipBackend.raytrace)."""
+    org = np.ascontiguousarray(org, np.float64).reshape(-1, 3)
+    dirs = np.ascontiguousarray(dirs, np.float64).reshape(-1, 3)
+    n = org.shape[0]
+    ins = None if inside is None else np.ascontiguousarray(inside, np.uint8)
+    rgb = np.zeros((n, 3))
+    d = scene.desc()
+    oracle().orc_raytrace_batch(C.byref(d), n, _d(org), _d(dirs), None if ins is None else ins.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                first_depth, bounces, seed, sample, stream_begin, _d(rgb))
+    return rgb
 
 
 def oracle_trace_pixel(scene: PackedScene, W, H, x, y, sample, bounces, seed=SEED_RENDER, with_segments=False):

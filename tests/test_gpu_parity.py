@@ -305,6 +305,69 @@ def test_renderer_api_end_to_end(backend):
     assert len(hits) == 1 and hits[0].obj is scene.objects[0]
 
 
+@pytest.mark.parametrize("scene,dump", [("room", "rays_room.npz"), ("random_spheres_seed7", "rays_random_spheres.npz"),
+                                        ("room_horse", "rays_room_horse.npz")])
+def test_raytrace_batch_against_oracle(backend, scene, dump):
+    """rt_raytrace_batch = Renderer.raytrace(ray, depth) for arbitrary rays (renderer.py:21-79):
+    upstream's own path segments (origin, direction, Ray.inside, depth) restarted as paths of their
+    own, with the same random stream on both sides.  Radiance agrees to float32 rounding
+    (1e-4 relative) except for paths that meet an edge within float32 resolution at a bounce
+    (module docstring): fewer than 1 % of the paths may differ."""
+    sc = _set(backend, scene)
+    z, _ = h.load_npz(dump)
+    n = 6000
+    org = z["org"][:n].astype(np.float32).astype(np.float64)
+    drs = z["dir"][:n].astype(np.float32).astype(np.float64)
+    inside = z["inside"][:n].astype(np.uint8)
+    for first_depth, bounces in ((0, 8), (3, 8), (9, 8)):
+        got = backend.raytrace(org, drs, bounces, h.SEED_RENDER, inside=inside, first_depth=first_depth, sample=5, stream_begin=100)
+        with h.origin_rule():
+            want = h.oracle_raytrace(sc, org, drs, bounces, h.SEED_RENDER, inside=inside, first_depth=first_depth, sample=5,
+                                     stream_begin=100)
+        assert np.isfinite(got).all()
+        if first_depth > bounces:
+            assert not got.any() and not want.any()
+            continue
+        off = np.abs(got - want).max(axis=1) > 1e-4 * (1.0 + np.abs(want).max(axis=1))
+        assert off.mean() < 0.01, f"{int(off.sum())} of {n} paths differ (first_depth {first_depth})"
+        assert want.max() > 0
+
+
+def test_renderer_raytrace_is_the_render_path(backend):
+    """Renderer.raytrace / raytrace_batch on camera rays with the render's own stream keys give the
+    image rt_render accumulates (one sample): the per-ray entry and the per-pixel kernel are the
+    same device functions."""
+    from raytracing_amd import raytracing
+
+    sc = _set(backend, "room")
+    W, H, bounces = 64, 36, 8
+    backend.resize(W, H)
+    backend.render(W, H, 2, 1, bounces, h.SEED_RENDER)
+    backend.synchronize()
+    img = backend.read()
+    cam = dict(pos=np.array(sc.cam_pos), right=np.array(sc.cam_right), up=np.array(sc.cam_up),
+               forward=np.array(sc.cam_forward), d=float(sc.cam_d))
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="ij")
+    u = (xs + 0.5) / W * 2 - 1
+    v = (ys + 0.5) / H * 2 * (H / W) - H / W
+    d = u[..., None] * cam["right"] + v[..., None] * cam["up"] + cam["d"] * cam["forward"]
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    org = np.broadcast_to(cam["pos"], d.shape)
+    got = backend.raytrace(org.reshape(-1, 3), d.reshape(-1, 3), bounces, h.SEED_RENDER, sample=2, stream_begin=0).reshape(W, H, 3)
+    off = np.abs(got - img).max(axis=2) > 1e-4 * (1.0 + img.max(axis=2))
+    assert off.mean() < 0.02, f"{int(off.sum())} of {off.size} pixels differ"
+
+    class _Settings:
+        MAX_BOUNCES = bounces
+    r = raytracing.Renderer(seed=h.SEED_RENDER)
+    r.render_settings = _Settings()
+    r._backend = backend
+    from raytracing_amd.core import Ray, Vec3
+    one = r.raytrace(Ray(Vec3(*cam["pos"]), Vec3(*d[W // 2, H // 2])), incoming_light=Vec3(1, 2, 3), ray_color=Vec3(0.5, 0.5, 0.5))
+    assert len(tuple(one)) == 3 and all(np.isfinite(tuple(one))) and tuple(one)[0] >= 1.0
+    assert tuple(r.raytrace(Ray(Vec3(0), Vec3(0, 0, 1)), depth=bounces + 1)) == (0.0, 0.0, 0.0)
+
+
 def test_parallelogram_rows_equal_triangle_rows(backend, monkeypatch):
     """Two triangles that share a diagonal are tested as one table row; the answers must be those of
     the per-triangle rows (switch RAYTRACING_AMD_NO_QUADS) and of the oracle - in particular ON the

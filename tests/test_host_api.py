@@ -150,7 +150,7 @@ def test_no_cpu_fallback():
     r = raytracing.Renderer()
     with pytest.raises(rtlib.BackendError):
         r.init_render(raytracing.RenderSettings(raytracing.Scene(), 8, 8, 1, 1))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(rtlib.BackendError):   # per-ray tracing goes to the GPU as well
         r.raytrace(core.Ray(core.Vec3(0), core.Vec3(0, 0, 1)))
     import raytracing_amd
 
