@@ -140,20 +140,46 @@ class Scene:
         return self.skybox.sample(ray.direction)
 
     # -- closest hit (GPU) ----------------------------------------------------------------------
+    def fingerprint(self) -> tuple:
+        """What the device copy of this scene depends on, cheap to compute (no vertex is read):
+        object identities and order, material values, sphere centres and radii, the identity of each
+        mesh's transformed-vertex and triangle arrays (the mesh setters - mesh.py:178-209 -
+        replace those arrays), camera and environment.  A changed fingerprint means the tables on
+        the GPU are stale."""
+        def mat(m):
+            return (tuple(m.color), float(m.emission_strength), float(m.smoothness), float(m.transmittance), float(m.ior))
+        objs = []
+        for o in self.objects:
+            if hasattr(o, "radius"):
+                objs.append((id(o), mat(o.material), tuple(o.origin), float(o.radius)))
+            else:
+                objs.append((id(o), mat(o.material), id(o.transformed_vertices), id(o.triangles)))
+        c = self.camera
+        cam = (tuple(c.pos), tuple(c.right), tuple(c.up), tuple(c.forward), float(c.d), float(c.dof_strength), float(c.dof_dist))
+        sky = None if self.skybox is None else (id(self.skybox.rgb), float(self.skybox.scale))
+        return (tuple(objs), cam, sky)
+
+    def update(self, t) -> None:
+        """Advance every object's animations to time ``t`` (base.py:17-19); the next query or render
+        re-packs the scene if that moved anything."""
+        for o in self.objects:
+            o.update(t)
+
     def _device_scene(self, device: int = 0):
         from .backend.lib import HipBackend
         from .backend.packer import pack_scene
 
-        key = (id(self.objects), len(self.objects), device)
+        key = (self.fingerprint(), device)
         if self._backend is None or self._packed_key != key:
-            be = HipBackend(device)
+            be = self._backend if (self._backend is not None and self._backend.device == device) else HipBackend(device)
             be.set_scene(pack_scene(self))
             self._backend, self._packed_key = be, key
         return self._backend
 
     def invalidate(self) -> None:
-        """Call after editing objects in place; the next query re-packs the scene."""
-        self._backend = None
+        """Force a re-pack on the next query (for edits the fingerprint cannot see, e.g. vertex
+        arrays modified in place)."""
+        self._packed_key = None
 
     def intersect_batch(self, origins, directions, origin_prim=None) -> dict:
         """Closest hit of many rays on the GPU (see ``HipBackend.intersect``)."""
@@ -278,18 +304,29 @@ class Renderer:
         self._backend = None
         self._thread: Optional[Thread] = None
         self._raytrace_calls = 0
+        self._scene_key = None
 
     # -- set-up ---------------------------------------------------------------------------------
     def init_render(self, render_settings: RenderSettings) -> None:
         from .backend.lib import HipBackend
         from .backend.packer import pack_scene
 
+        if self._thread is not None and self._thread.is_alive():   # a render of this renderer is still running
+            self.stop_render()
+            self._thread.join()
         self.render_settings = render_settings
         self.render_result = RenderResult(render_settings.WIDTH, render_settings.HEIGHT, render_settings.RENDER_PASSES)
         self.scene = render_settings.SCENE
         self.stop_event.clear()
-        be = HipBackend(self.device)
-        be.set_scene(pack_scene(self.scene))
+        # One context per renderer, kept across renders; the scene tables are uploaded again only
+        # when the scene changed (objects moved by the mesh setters, materials, camera, environment).
+        be = self._backend if self._backend is not None else HipBackend(self.device)
+        key = (id(self.scene), self.scene.fingerprint())
+        if self._scene_key != key:
+            be.set_scene(pack_scene(self.scene))
+            self._scene_key = key
+        be.clear_stop()
+        be.reset_stats()
         be.resize(render_settings.WIDTH, render_settings.HEIGHT)
         self._backend = be
         self.render_result._backend = be

@@ -368,6 +368,93 @@ def test_renderer_raytrace_is_the_render_path(backend):
     assert tuple(r.raytrace(Ray(Vec3(0), Vec3(0, 0, 1)), depth=bounces + 1)) == (0.0, 0.0, 0.0)
 
 
+def test_progressive_app_loop_headless(backend, tmp_path):
+    """The preview loop of upstream's main.py:165-231 without a window: background render, polled
+    progress captions, post-processed PNG written once at the end."""
+    from PIL import Image
+
+    from raytracing_amd import app, post_processing, raytracing
+    from raytracing_amd.core import Material, Vec3
+    from raytracing_amd.mesh import Sphere
+
+    scene = raytracing.Scene()
+    scene.add_object(Sphere(Material(Vec3(0.9, 0.3, 0.3), 0, 0.2, 0, 1.45), Vec3(0, 0, 3), 1.0))
+    scene.add_object(Sphere(Material(Vec3(1), 3.0, 0, 0, 1.0), Vec3(0, 5, 3), 2.0))
+    scene.add_object(Sphere(Material(Vec3(0.8), 0, 0, 0, 1.0), Vec3(0, -1001, 3), 1000.0))
+    scene.camera = raytracing.Camera(Vec3(0, 0.5, -2), np.pi / 3, Vec3(0, 0, 3))
+    settings = raytracing.RenderSettings(scene, 128, 72, 64, 4)
+    pp = post_processing.PostProcessing(exposure=2, brightness=0.02, contrast=1.1)
+    texts = []
+    out = tmp_path / "renders" / "x.png"
+    res, final = app.run(settings, pp, str(out), on_tick=texts.append, seed=11)
+    assert res.finished and res.rendered_passes == 64 and abs(res.progress_percent - 100.0) < 1e-9
+    assert texts and all(t.startswith("rendering: ") and " / " in t for t in texts)
+    assert np.allclose(final, pp.process(res.img_arr))
+    png = np.asarray(Image.open(out))
+    assert png.shape == (72, 128, 3)
+    assert np.array_equal(png, np.transpose(np.clip(final * 255.0, 0, 255).astype(np.uint8), (1, 0, 2)))
+    # the same settings rendered in one call give the same sums: progressive batches only split the sample range
+    r2 = raytracing.Renderer(seed=11)
+    r2.init_render(settings)
+    r2.render()
+    assert np.allclose(r2.render_result.arr, res.arr, rtol=1e-5, atol=1e-5)
+
+
+def test_moved_objects_are_uploaded_again(backend):
+    """Dynamic scenes (mesh setters, mesh.py:178-209; ObjectBase.update, base.py:17-19): after an
+    object moves, queries and renders see the new geometry without any explicit call, and equal
+    those of a scene built at the new position from scratch."""
+    from raytracing_amd import raytracing
+    from raytracing_amd.core import Material, Ray, Vec3
+    from raytracing_amd.mesh import Mesh, Sphere
+
+    def build(offset, rot):
+        sc = raytracing.Scene()
+        sc.add_object(Sphere(Material(Vec3(1), 2.0, 0, 0, 1.0), Vec3(0, 6, 3), 2.0))
+        sc.add_object(Mesh(Material(Vec3(0.8, 0.8, 0.3), 0, 0.1, 0, 1.0), Vec3(*offset),
+                           [(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], [(0, 1, 2), (0, 2, 3)], rotation=Vec3(*rot)))
+        sc.add_object(Sphere(Material(Vec3(0.7), 0, 0, 0, 1.0), Vec3(0, -1001, 3), 1000.0))
+        sc.camera = raytracing.Camera(Vec3(0, 0.5, -3), np.pi / 3, Vec3(0, 0, 3))
+        return sc
+
+    class Spin:
+        def __init__(self, mesh):
+            self.mesh = mesh
+
+        def update(self, t):
+            self.mesh.set_rotation(Vec3(0, 30.0 * t, 0))
+
+    scene = build((0, 0, 3), (0, 0, 0))
+    ray = Ray(Vec3(0.5, 0.2, -3), Vec3(0, 0, 1))
+    first = scene.intersect(ray)
+    assert first and first[0].obj is scene.objects[1] and abs(first[0].depth - 6.0) < 1e-9
+    ctx = scene._backend
+    scene.objects[1].set_origin(Vec3(0, 0, 5))
+    moved = scene.intersect(ray)
+    assert moved[0].obj is scene.objects[1] and abs(moved[0].depth - 8.0) < 1e-9
+    assert scene._backend is ctx                     # same context, new tables
+    scene.objects[1].animations.append(Spin(scene.objects[1]))
+    scene.update(1.0)
+    turned = scene.intersect(ray)
+    fresh = build((0, 0, 5), (0, 30.0, 0))
+    want = fresh.intersect(ray)
+    assert turned[0].primitive == want[0].primitive and abs(turned[0].depth - want[0].depth) <= 1e-12 * want[0].depth
+    assert abs(turned[0].depth - 8.0) > 0.1
+
+    settings = raytracing.RenderSettings(scene, 64, 36, 8, 4)
+    r = raytracing.Renderer(seed=5)
+    r.init_render(settings); r.render()
+    a = r.render_result.arr.copy()
+    scene.objects[1].set_origin(Vec3(0.5, 0, 4))
+    r.init_render(settings); r.render()              # same renderer, same context, scene changed
+    b = r.render_result.arr.copy()
+    r2 = raytracing.Renderer(seed=5)
+    fresh2 = build((0.5, 0, 4), (0, 30.0, 0))
+    r2.init_render(raytracing.RenderSettings(fresh2, 64, 36, 8, 4)); r2.render()
+    assert np.abs(a - b).max() > 0.05
+    assert np.array_equal(b, r2.render_result.arr)
+
+
 def test_parallelogram_rows_equal_triangle_rows(backend, monkeypatch):
     """Two triangles that share a diagonal are tested as one table row; the answers must be those of
     the per-triangle rows (switch RAYTRACING_AMD_NO_QUADS) and of the oracle - in particular ON the

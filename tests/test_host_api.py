@@ -254,3 +254,24 @@ def test_native_obj_reader_equals_the_python_statement(tmp_path):
     assert mesh.Mesh.load_from_obj_file(str(q)) == [] and mesh.Mesh._parse_obj_native(str(q)) == []
     with pytest.raises(ValueError):
         mesh.Mesh._parse_obj_native(str(tmp_path / "missing.obj"))
+
+
+def test_app_helpers(tmp_path):
+    """Caption / time formatting of the preview loop (main.py:13-15, 225-228) and the PNG writer's
+    orientation: (W, H, 3) in, image of width W and height H out."""
+    from PIL import Image
+
+    from raytracing_amd import app
+
+    assert app.convert_seconds(0) == "00:00:00" and app.convert_seconds(3725.9) == "01:02:05"
+    assert app.convert_seconds(25 * 3600 + 61) == "01:01:01"   # hours wrap at 24 as upstream's do
+
+    class R:
+        progress_percent = 12.345678
+    assert app.caption(R(), 5, 40) == "rendering: 12.3457%, estimated 00:00:05 / 00:00:40"
+    img = np.zeros((7, 4, 3))
+    img[6, 0] = (1.0, 0.5, 2.0)      # x = 6, y = 0; values above 1 clip
+    p = tmp_path / "o.png"
+    app.save_image(img, str(p))
+    back = np.asarray(Image.open(p))
+    assert back.shape == (4, 7, 3) and tuple(back[0, 6]) == (255, 127, 255) and back.sum() == 255 + 127 + 255
