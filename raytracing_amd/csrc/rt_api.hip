@@ -292,7 +292,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         double nl = norm(N);
         TriRow r{}; TriAux x{};
         const int m = tri_mesh[t];
-        x.obj = d->mesh_obj[m]; x.face = t - d->mesh_tri_begin[m]; x.mesh = m;
+        x.obj = d->mesh_obj[m]; x.face = t - d->mesh_tri_begin[m]; x.mesh = m; x.pair_row = -1;
         r.gprim = d->n_spheres + t;
         // |det| = |d.N| <= |d||N|: with |d| <= 2 (longer rays use the exact code) a triangle with
         // |N| < 4e-7 can never pass upstream's |det| >= 1e-6 cut, nor can a non-finite one.
@@ -407,6 +407,8 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
                 r.gprim = kQuadFlag | ((d->n_spheres + y) << kQuadIdBits) | (d->n_spheres + t);
                 taken[y] = 1;
                 ++n_live_tris;
+                aux[t].pair_row = (int32_t)rows_quad.size();
+                aux[t].det_hi = aux[y].det_hi = std::max(aux[t].det_hi, aux[y].det_hi);
                 break;
             }
             ((r.gprim & kQuadFlag) ? rows_quad : rows_live).push_back(r);

@@ -159,6 +159,7 @@ RT_DEV TriEval tri_eval(const TriRow &T, const Ray &r) {
 // First pass, scenes of up to 4096 primitives: best and runner-up as 32-bit keys
 // (bits of t_lo with the low bits cleared) | id.  Three instructions per primitive.
 struct KeyBest {
+    static constexpr bool kPerTriangle = false;   // a parallelogram row is ONE candidate (its first triangle's id)
     uint32_t k0, k1, keep_mask, id_mask;
     RT_DEV void init(const DevScene &S) { k0 = k1 = 0xFFFFFFFFu; id_mask = S.key_mask; keep_mask = ~S.key_mask; }
     RT_DEV void operator()(float tl, int32_t id) {
@@ -179,6 +180,7 @@ struct KeyBest {
 // primitive that is CERTAINLY hit; nothing that starts beyond it can be the closest hit or tie
 // with it, which is what lets the hierarchy walk skip boxes.
 struct PairBest {
+    static constexpr bool kPerTriangle = true;
     float lo0, lo1, tmax; int32_t id0;
     RT_DEV void init(const DevScene &) { lo0 = lo1 = tmax = kInf; id0 = -1; }
     RT_DEV void operator()(float tl, int32_t id) {
@@ -207,6 +209,7 @@ RT_DEV uint64_t scene_order(const DevScene &S, int32_t gprim) {
 // then face order: scene.py:23-27, mesh.py:101-110) is the hit.  A primitive whose t_lo is above
 // `limit` has a true depth beyond a proven hit and cannot win or tie.
 struct Resolve {
+    static constexpr bool kPerTriangle = true;
     const DevScene *S;
     D3 o, d;
     int32_t origin, skip;      // skip: the first-pass winner, already evaluated
@@ -264,7 +267,7 @@ RT_DEV float tri_tlo(const TriRow &T, const Ray &r, float *sure_thi) {
 constexpr int32_t kQuadFlag = 1 << 30;
 constexpr int32_t kQuadIdBits = 13;
 
-struct RowEval { float u, v, w, bb, thi, tlo; bool dead; };
+struct RowEval { float u, v, w, bb, t, thi, tlo, nd_abs; bool dead; };
 
 RT_DEV RowEval row_eval(const TriRow &T, const Ray &r) {
     RowEval e;
@@ -278,10 +281,12 @@ RT_DEV RowEval row_eval(const TriRow &T, const Ray &r) {
     e.w = (1.0f - e.u) - e.v;
     const float g = fma_(r.c7, abs_(t), r.c4) * abs_(inv);
     e.bb = g * T.cb;
+    e.t = t;
     e.thi = fma_(g, T.ct, t);
     e.tlo = fma_(-g, T.ct, t);
+    e.nd_abs = abs_(nd);
     // det_lo = +inf marks the padding rows at the end of a table: never candidates (NaN included)
-    e.dead = !(abs_(nd) >= T.det_lo);
+    e.dead = !(e.nd_abs >= T.det_lo);
     return e;
 }
 
@@ -298,16 +303,28 @@ RT_DEV void tri_row_candidates(const TriRow &T, const Ray &r, Sink &sink) {
     sink((e.dead || T.gprim == r.origin) ? kInf : tl, T.gprim);
 }
 
+// Margin of a point with first-triangle coordinates (u, v, w = 1 - u - v) inside the parallelogram.
+RT_DEV float pair_margin(const RowEval &e) { return min_(min_(e.v, 1.0f - e.v), min_(e.u + e.v, e.w)); }
+
 template <class Sink>
 RT_DEV void quad_row_candidates(const TriRow &T, const Ray &r, Sink &sink) {
     const RowEval e = row_eval(T, r);
     const int32_t id1 = T.gprim & ((1 << kQuadIdBits) - 1), id2 = (T.gprim >> kQuadIdBits) & ((1 << kQuadIdBits) - 1);
-    const float tl = row_tl(e, min_(min_(e.v, 1.0f - e.v), min_(e.u + e.v, e.w)));
-    const bool first = e.u >= 0.0f;
-    const int32_t idp = first ? id1 : id2, ido = first ? id2 : id1;
-    const bool clear = abs_(e.u) > e.bb;         // false for NaN: then both are reported
-    sink((e.dead || idp == r.origin) ? kInf : tl, idp);
-    sink((e.dead || clear || ido == r.origin) ? kInf : tl, ido);
+    const float tl = row_tl(e, pair_margin(e));
+    if (Sink::kPerTriangle) {
+        const bool first = e.u >= 0.0f;
+        const int32_t idp = first ? id1 : id2, ido = first ? id2 : id1;
+        const bool clear = abs_(e.u) > e.bb;         // false for NaN: then both are reported
+        sink((e.dead || idp == r.origin) ? kInf : tl, idp);
+        sink((e.dead || clear || ido == r.origin) ? kInf : tl, ido);
+    } else {
+        // One candidate for the pair, under the first triangle's id; which of the two it is gets
+        // decided once, for the winner (judge_tri).  A ray that starts on one of the two cannot hit
+        // that one again: the row is out when the crossing point is clearly on the origin's side of
+        // the diagonal (inside the band it stays, and the double-precision code sorts it out).
+        const bool own = (id1 == r.origin && e.u > e.bb) || (id2 == r.origin && e.u < -e.bb);
+        sink((e.dead || own) ? kInf : tl, id1);
+    }
 }
 
 // Brute-force loops over the two linear tables (parallelogram rows, then triangle rows), two rows
@@ -426,15 +443,30 @@ RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters 
 
 // Winner re-evaluation.  status: 0 accept float32 result, 1 identity certain but imprecise,
 // 2 undecided (ask the exact code about this primitive).
-struct Verdict { int status; float t, thi; };
+struct Verdict { int status; float t, thi; int32_t ti; bool open; };
 
+// `ti` = triangle index the first pass named.  With PAIRS (first passes that report a parallelogram
+// row as one candidate) a triangle that heads such a row stands for the pair: the row itself is
+// evaluated, the side of the diagonal names the triangle (Verdict::ti), and a crossing point within
+// the error band of the diagonal leaves it open (Verdict::open: both go to the double-precision
+// tie-break, scene.py:24-27).
+template <bool PAIRS>
 RT_DEV Verdict judge_tri(const DevScene &S, int32_t ti, const Ray &r, float rel_accept, float abs_accept) {
-    const TriRow T = S.tri_by_id[ti];
-    TriEval e = tri_eval(T, r);
-    float bb = e.g * T.cb, bt = e.g * T.ct;
-    bool certain = (e.m - bb >= 0.0f) && (e.t - bt > kTCertain) && (abs_(e.nd) >= S.tri_aux[ti].det_hi);
+    const TriAux X = S.tri_aux[ti];
+    const bool pair = PAIRS && X.pair_row >= 0;
+    const TriRow T = pair ? S.quad_rows[X.pair_row] : S.tri_by_id[ti];
+    const RowEval e = row_eval(T, r);
+    const float m = pair ? pair_margin(e) : min_(min_(e.u, e.v), e.w);
+    const float bt = e.thi - e.t;
     Verdict v;
-    v.t = e.t; v.thi = e.t + bt;
+    v.ti = ti; v.open = false;
+    if (pair) {
+        const int32_t id2 = (T.gprim >> kQuadIdBits) & ((1 << kQuadIdBits) - 1);
+        if (e.u < -e.bb) v.ti = id2 - S.n_spheres;
+        else if (!(e.u > e.bb)) v.open = true;
+    }
+    const bool certain = !e.dead && !v.open && (m - e.bb >= 0.0f) && (e.tlo > kTCertain) && (e.nd_abs >= X.det_hi);
+    v.t = e.t; v.thi = e.thi;
     v.status = !certain ? 2 : ((bt <= max_(rel_accept * e.t, abs_accept)) ? 0 : 1);
     return v;
 }
@@ -647,6 +679,7 @@ RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, cons
     const int route = ray_route<TRI>(r);
     int32_t gprim = -1; int root = 0; float t = kInf;
     int status = 0; float thi = kInf, second_lo = kInf; bool has_second = false;
+    bool pair_open = false;   // the winner is a parallelogram row hit within the error band of its diagonal
     // absolute depth tolerance of the render kernel (see kAbsAcceptRender); none for the closest-hit entry
     const float abs_accept = STRICT ? 0.0f : kAbsAcceptRender * (r.o2 + S.scene_radius);
     if (route == kRouteFilter && first.any()) {
@@ -666,8 +699,9 @@ RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, cons
                 status = v.status; t = v.t; thi = v.thi; root = v.root;
             }
         } else {
-            Verdict v = judge_tri(S, gprim - S.n_spheres, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
-            status = v.status; t = v.t; thi = v.thi;
+            const Verdict v = judge_tri<!FirstPass<TRI>::type::kPerTriangle>(S, gprim - S.n_spheres, r,
+                                                                             STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
+            status = v.status; t = v.t; thi = v.thi; gprim = S.n_spheres + v.ti; pair_open = v.open;
         }
     }
     const bool settle = route != kRouteFilter || (gprim >= 0 && (status != 0 || (has_second && !(second_lo > thi))));
@@ -677,8 +711,11 @@ RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, cons
         const D3 o64 = x64.o, d64 = x64.d;
         const bool scan = route == kRouteScan;
         bool second = route == kRouteOpen; float limit = kInf;
-        const int32_t skip = gprim;
-        if (route == kRouteFilter) {
+        int32_t skip = gprim;
+        if (route == kRouteFilter && pair_open) {
+            // either triangle of the pair, or a contender: the second pass evaluates them all
+            second = true; limit = kInf; gprim = -1; skip = -1;
+        } else if (route == kRouteFilter) {
             if (status == 1 && gprim >= S.n_spheres) {
                 // a triangle that is certainly the hit but whose float32 depth is too coarse (grazing
                 // incidence, or a very short ray): only the depth is redone in double precision

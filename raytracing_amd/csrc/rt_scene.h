@@ -34,7 +34,7 @@ struct TriAux {
     int32_t obj;        // index into scene.objects
     int32_t face;       // face index inside its mesh
     int32_t mesh;       // mesh index (for the bounding-box gate of the exact code)
-    int32_t pad;
+    int32_t pair_row;   // index into quad_rows of the parallelogram row this triangle heads (it is the row's first), else -1
 };
 
 // One small sphere, 8 dwords = one s_load_dwordx8.
