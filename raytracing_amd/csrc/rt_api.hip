@@ -63,7 +63,7 @@ struct rt_ctx {
     bool has_scene = false;
     DevScene S{};
     int tri_mode = 0; bool has_sph = false;
-    DevBuf tri_rows, quad_rows, leaf_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
+    DevBuf tri_rows, quad_rows, slab_rows, leaf_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
@@ -366,6 +366,10 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     // rebuilt for the vertex order that puts the shared edge at a-c, with both bound constants
     // widened by 1e-3, far more than the tolerance (see row_candidates).
     std::vector<TriRow> rows_live, rows_quad;
+    // per parallelogram row: its first triangle, the axis its plane is perpendicular to (-1: none),
+    // the plane's coordinate on that axis and |N| of the row's plane functional
+    struct PairInfo { int tri; int axis; double c0, nl; };
+    std::vector<PairInfo> pair_info;
     int n_live_tris = 0;
     {
         const bool merge_pairs = std::getenv("RAYTRACING_AMD_NO_QUADS") == nullptr;   // switch for A/B runs and tests
@@ -407,12 +411,55 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
                 r.gprim = kQuadFlag | ((d->n_spheres + y) << kQuadIdBits) | (d->n_spheres + t);
                 taken[y] = 1;
                 ++n_live_tris;
-                aux[t].pair_row = (int32_t)rows_quad.size();
                 aux[t].det_hi = aux[y].det_hi = std::max(aux[t].det_hi, aux[y].det_hi);
+                int axis = -1;
+                if (N.y == 0 && N.z == 0) axis = 0; else if (N.x == 0 && N.z == 0) axis = 1; else if (N.x == 0 && N.y == 0) axis = 2;
+                const double c0 = axis == 0 ? a.x : (axis == 1 ? a.y : a.z);
+                // the compact form reads e1/e2 without their component along the axis: it must be exactly zero
+                if (axis >= 0 && ((axis == 0 && (r.e1x != 0 || r.e2x != 0)) || (axis == 1 && (r.e1y != 0 || r.e2y != 0)) ||
+                                  (axis == 2 && (r.e1z != 0 || r.e2z != 0)))) axis = -1;
+                if (std::getenv("RAYTRACING_AMD_NO_SLABS")) axis = -1;   // switch for A/B runs and tests
+                pair_info.push_back({t, axis, c0, nl});
                 break;
             }
             ((r.gprim & kQuadFlag) ? rows_quad : rows_live).push_back(r);
         }
+    }
+    // Parallelogram rows in general position first, then those in axis-perpendicular planes (by axis);
+    // the latter also get their compact form.  At most 1023 per axis (the counts share one word).
+    std::vector<SlabRow> rows_slab;
+    int n_quad_general = 0;
+    uint32_t slab_counts = 0;
+    {
+        int per_axis[3] = {0, 0, 0};
+        for (auto &pi : pair_info) if (pi.axis >= 0 && ++per_axis[pi.axis] > 1023) { pi.axis = -1; }
+        std::vector<int> order;
+        for (int pass = -1; pass < 3; ++pass)
+            for (int k = 0; k < (int)pair_info.size(); ++k) if (pair_info[k].axis == pass) order.push_back(k);
+        std::vector<TriRow> sorted(rows_quad.size());
+        int counts[3] = {0, 0, 0};
+        for (int k = 0; k < (int)order.size(); ++k) {
+            const PairInfo &pi = pair_info[order[k]];
+            const TriRow &q = rows_quad[order[k]];
+            sorted[k] = q;
+            aux[pi.tri].pair_row = k;
+            if (pi.axis < 0) { ++n_quad_general; continue; }
+            ++counts[pi.axis];
+            SlabRow sr{};
+            sr.c0 = (float)pi.c0;
+            const float e1[3] = {q.e1x, q.e1y, q.e1z}, e2[3] = {q.e2x, q.e2y, q.e2z};
+            const int b = pi.axis == 0 ? 1 : 0, cc = pi.axis == 2 ? 1 : 2;
+            sr.e1b = e1[b]; sr.e1c = e1[cc]; sr.k1 = q.k1; sr.e2b = e2[b]; sr.e2c = e2[cc]; sr.k2 = q.k2;
+            // bound constants for a unit normal: the general row's divided by |N|
+            sr.cb = up(1.000001 * (double)q.cb / pi.nl);
+            sr.ct = up(1.000001 * (double)q.ct / pi.nl);
+            sr.det_lo = (float)((double)q.det_lo / pi.nl) * (1.0f - 4.0f * kU);
+            sr.gprim = q.gprim;
+            rows_slab.push_back(sr);
+        }
+        rows_quad.swap(sorted);
+        slab_counts = (uint32_t)counts[0] | ((uint32_t)counts[1] << 10) | ((uint32_t)counts[2] << 20);
+        if (!rows_slab.empty()) { SlabRow dead{}; dead.k1 = dead.k2 = -1; dead.det_lo = INFINITY; dead.gprim = kQuadFlag; rows_slab.push_back(dead); }
     }
     // ---- materials, environment ---------------------------------------------------------------
     std::vector<MatRow> mats(d->n_objects);
@@ -451,7 +498,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         while (tab->size() % 2) tab->push_back(dead);
         for (int k = 0; k < 2; ++k) tab->push_back(dead);
     }
-    HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->leaf_rows.upload(rows_leaf)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
+    HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->slab_rows.upload(rows_slab)); HIP_TRY(c, c->leaf_rows.upload(rows_leaf)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
     HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
     HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));
     HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
@@ -476,6 +523,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S = DevScene{};
     S.tri_rows = c->tri_rows.as<TriRow>(); S.n_tri_rows = n_live; S.n_tri_rows_padded = any_tri_rows ? (int)rows_live.size() - 2 : 0;
     S.quad_rows = c->quad_rows.as<TriRow>(); S.n_quad_rows_padded = any_quad_rows ? (int)rows_quad.size() - 2 : 0;
+    S.slab_rows = c->slab_rows.as<SlabRow>(); S.n_quad_general = n_quad_general; S.slab_counts = slab_counts;
     S.sph_rows = c->sph_rows.as<SphRow>(); S.n_sph_rows = (int)sph_small.size();
     S.big_sph = c->big_sph.as<int32_t>(); S.n_big_sph = (int)big.size();
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();

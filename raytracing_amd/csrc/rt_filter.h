@@ -70,6 +70,19 @@ RT_DEV SphRow load_sph_row_uniform(const SphRow *rows, int i) {
     return P;
 }
 
+RT_DEV SlabRow load_slab_row_uniform(const SlabRow *rows, int i) {
+    const_f4_ptr q = as_const_f4(rows) + 3 * (size_t)i;
+    f4 a = q[0], b = q[1], c = q[2];
+    SlabRow T;
+    T.c0 = a.x; T.e1b = a.y; T.e1c = a.z; T.k1 = a.w;
+    T.e2b = b.x; T.e2c = b.y; T.k2 = b.z; T.cb = b.w;
+    T.ct = c.x; T.det_lo = c.y;
+    const float id_bits = c.z;
+    T.gprim = (int32_t)f2u(id_bits);
+    T.pad = 0;
+    return T;
+}
+
 constexpr uint32_t kKeyNone = 0x7F800000u;   // keys at or above +inf's pattern mean "no candidate"
 constexpr float kInf = __builtin_inff();
 constexpr float kTCertain = 1e-9f;           // a depth bound above this certainly passes upstream's 1e-10 filter
@@ -306,24 +319,67 @@ RT_DEV void tri_row_candidates(const TriRow &T, const Ray &r, Sink &sink) {
 // Margin of a point with first-triangle coordinates (u, v, w = 1 - u - v) inside the parallelogram.
 RT_DEV float pair_margin(const RowEval &e) { return min_(min_(e.v, 1.0f - e.v), min_(e.u + e.v, e.w)); }
 
+// A parallelogram as ONE candidate, under its first triangle's id; which of the two triangles it is
+// gets decided once, for the winner (judge_tri).  A ray that starts on one of the two cannot hit that
+// one again: the row is out when the crossing point is clearly on the origin's side of the diagonal
+// (inside the band it stays, and the double-precision code sorts it out).
+template <class Sink>
+RT_DEV void pair_candidate(const RowEval &e, int32_t id_word, const Ray &r, Sink &sink) {
+    const int32_t id1 = id_word & ((1 << kQuadIdBits) - 1), id2 = (id_word >> kQuadIdBits) & ((1 << kQuadIdBits) - 1);
+    const float tl = row_tl(e, pair_margin(e));
+    const bool own = (id1 == r.origin && e.u > e.bb) || (id2 == r.origin && e.u < -e.bb);
+    sink((e.dead || own) ? kInf : tl, id1);
+}
+
 template <class Sink>
 RT_DEV void quad_row_candidates(const TriRow &T, const Ray &r, Sink &sink) {
     const RowEval e = row_eval(T, r);
-    const int32_t id1 = T.gprim & ((1 << kQuadIdBits) - 1), id2 = (T.gprim >> kQuadIdBits) & ((1 << kQuadIdBits) - 1);
-    const float tl = row_tl(e, pair_margin(e));
     if (Sink::kPerTriangle) {
+        const int32_t id1 = T.gprim & ((1 << kQuadIdBits) - 1), id2 = (T.gprim >> kQuadIdBits) & ((1 << kQuadIdBits) - 1);
+        const float tl = row_tl(e, pair_margin(e));
         const bool first = e.u >= 0.0f;
         const int32_t idp = first ? id1 : id2, ido = first ? id2 : id1;
         const bool clear = abs_(e.u) > e.bb;         // false for NaN: then both are reported
         sink((e.dead || idp == r.origin) ? kInf : tl, idp);
         sink((e.dead || clear || ido == r.origin) ? kInf : tl, ido);
     } else {
-        // One candidate for the pair, under the first triangle's id; which of the two it is gets
-        // decided once, for the winner (judge_tri).  A ray that starts on one of the two cannot hit
-        // that one again: the row is out when the crossing point is clearly on the origin's side of
-        // the diagonal (inside the band it stays, and the double-precision code sorts it out).
-        const bool own = (id1 == r.origin && e.u > e.bb) || (id2 == r.origin && e.u < -e.bb);
-        sink((e.dead || own) ? kInf : tl, id1);
+        pair_candidate(e, T.gprim, r, sink);
+    }
+}
+
+// The same parallelogram test for a row in a plane perpendicular to axis AXIS (SlabRow): the general
+// row's arithmetic with N = the axis unit vector, so every bound of the error model above holds with
+// room to spare (N.d is exact, N.o + kN is one subtraction).  `inv` = 1 / d_AXIS, once per ray.
+template <int AXIS>
+RT_DEV RowEval slab_eval(const SlabRow &T, const Ray &r, float inv) {
+    const float oa = AXIS == 0 ? r.ox : (AXIS == 1 ? r.oy : r.oz), da = AXIS == 0 ? r.dx : (AXIS == 1 ? r.dy : r.dz);
+    const float ob = AXIS == 0 ? r.oy : r.ox, db = AXIS == 0 ? r.dy : r.dx;
+    const float oc = AXIS == 2 ? r.oy : r.oz, dc = AXIS == 2 ? r.dy : r.dz;
+    RowEval e;
+    const float t = (T.c0 - oa) * inv;
+    const float pb = fma_(t, db, ob), pc = fma_(t, dc, oc);
+    e.u = fma_(T.e1c, pc, fma_(T.e1b, pb, T.k1));
+    e.v = fma_(T.e2c, pc, fma_(T.e2b, pb, T.k2));
+    e.w = (1.0f - e.u) - e.v;
+    const float g = fma_(r.c7, abs_(t), r.c4) * abs_(inv);
+    e.bb = g * T.cb;
+    e.t = t;
+    e.thi = fma_(g, T.ct, t);
+    e.tlo = fma_(-g, T.ct, t);
+    e.nd_abs = abs_(da);
+    e.dead = !(e.nd_abs >= T.det_lo);
+    return e;
+}
+
+template <int AXIS, class Sink>
+RT_DEV void slab_loop(const SlabRow *rows, int begin, int n, const Ray &r, Sink &sink) {
+    if (n <= 0) return;
+    const float inv = rcp_(AXIS == 0 ? r.dx : (AXIS == 1 ? r.dy : r.dz));
+    SlabRow cur = load_slab_row_uniform(rows, begin);
+    for (int i = 0; i < n; ++i) {
+        const SlabRow next = load_slab_row_uniform(rows, begin + i + 1);   // the table ends with a dead row
+        pair_candidate(slab_eval<AXIS>(cur, r, inv), cur.gprim, r, sink);
+        cur = next;
     }
 }
 
@@ -334,13 +390,22 @@ RT_DEV void quad_row_candidates(const TriRow &T, const Ray &r, Sink &sink) {
 template <class Sink>
 RT_DEV void search_tris(const DevScene &S, const Ray &r, Sink &sink) {
     if (S.n_quad_rows_padded > 0) {
-        const int n = S.n_quad_rows_padded;
+        // one candidate per parallelogram: only the rows in general position; the rest follow in compact form
+        const int n = Sink::kPerTriangle ? S.n_quad_rows_padded : S.n_quad_general;
         const TriRow *rows = S.quad_rows;
-        TriRow cur = load_tri_row_uniform(rows, 0);
-        for (int i = 0; i < n; ++i) {
-            const TriRow next = load_tri_row_uniform(rows, i + 1);
-            quad_row_candidates(cur, r, sink);
-            cur = next;
+        if (n > 0) {
+            TriRow cur = load_tri_row_uniform(rows, 0);
+            for (int i = 0; i < n; ++i) {
+                const TriRow next = load_tri_row_uniform(rows, i + 1);
+                quad_row_candidates(cur, r, sink);
+                cur = next;
+            }
+        }
+        if (!Sink::kPerTriangle && S.slab_counts != 0) {
+            const int nx = (int)(S.slab_counts & 1023u), ny = (int)((S.slab_counts >> 10) & 1023u), nz = (int)(S.slab_counts >> 20);
+            slab_loop<0>(S.slab_rows, 0, nx, r, sink);
+            slab_loop<1>(S.slab_rows, nx, ny, r, sink);
+            slab_loop<2>(S.slab_rows, nx + ny, nz, r, sink);
         }
     }
     if (S.n_tri_rows_padded > 0) {

@@ -27,6 +27,18 @@ struct TriRow {
     int32_t gprim;  // global primitive id = n_spheres + triangle index
 };
 
+// A parallelogram row whose plane is perpendicular to a coordinate axis a (walls, floors, box faces),
+// in compact form, 12 dwords: t = (c0 - o_a) / d_a needs no dot products and shares one reciprocal
+// per ray and axis; (b, c) are the other two axes in increasing order, u = e1b p_b + e1c p_c + k1,
+// v likewise.  Bound constants as in TriRow, for a unit plane normal.
+struct SlabRow {
+    float c0, e1b, e1c, k1;
+    float e2b, e2c, k2, cb;
+    float ct, det_lo;   // det_lo: |d_a| below this can never pass upstream's |det| cut
+    int32_t gprim;      // id word of the parallelogram row (see kQuadFlag)
+    int32_t pad;
+};
+
 // Data needed once a triangle has won: unit normal (mesh.py:140), owner, certain-accept cut.
 struct TriAux {
     float nx, ny, nz;   // normalize(ab x ac), rounded from double
@@ -75,6 +87,10 @@ struct DevScene {
                                                       // rows are padded with dead ones:
     int32_t n_tri_rows_padded;                        //   even, and 2 more rows exist past it
     const TriRow *quad_rows;  int32_t n_quad_rows_padded;   // parallelogram rows (two triangles each), padded likewise
+    // First passes that take one candidate per parallelogram walk quad_rows[0, n_quad_general) and, for
+    // the rows behind those - the ones in axis-perpendicular planes - the compact table instead:
+    const SlabRow *slab_rows; int32_t n_quad_general;
+    uint32_t slab_counts;     // rows per axis: x | y << 10 | z << 20, stored in that order, one dead row at the end
     const SphRow *sph_rows;   int32_t n_sph_rows;     // small spheres only
     const int32_t *big_sph;   int32_t n_big_sph;      // sphere indices evaluated in float64
     const TriRow *tri_by_id;                          // [n_tris] same rows, indexed by triangle id
