@@ -171,10 +171,18 @@ RT_DEV TriEval tri_eval(const TriRow &T, const Ray &r) {
 
 // First pass, scenes of up to 4096 primitives: best and runner-up as 32-bit keys
 // (bits of t_lo with the low bits cleared) | id.  Three instructions per primitive.
+template <bool VECTOR_MASK>
 struct KeyBest {
     static constexpr bool kPerTriangle = false;   // a parallelogram row is ONE candidate (its first triangle's id)
     uint32_t k0, k1, keep_mask, id_mask;
-    RT_DEV void init(const DevScene &S) { k0 = k1 = 0xFFFFFFFFu; id_mask = S.key_mask; keep_mask = ~S.key_mask; }
+    RT_DEV void init(const DevScene &S) {
+        k0 = k1 = 0xFFFFFFFFu; id_mask = S.key_mask;
+        // the mask lives in a VECTOR register: (bits & mask) | id is then one v_and_or_b32 with the row's id
+        // as its single scalar operand (two scalar operands would need a second instruction per row)
+        // (measured: it pays in the triangle loops, not in a spheres-only kernel)
+        if (VECTOR_MASK) asm volatile("v_mov_b32 %0, %1" : "=v"(keep_mask) : "s"(~S.key_mask));
+        else keep_mask = ~S.key_mask;
+    }
     RT_DEV void operator()(float tl, int32_t id) {
         const uint32_t key = (f2u(tl) & keep_mask) | (uint32_t)id;
         k1 = umed3_(k0, k1, key);
@@ -317,7 +325,10 @@ RT_DEV void tri_row_candidates(const TriRow &T, const Ray &r, Sink &sink) {
 }
 
 // Margin of a point with first-triangle coordinates (u, v, w = 1 - u - v) inside the parallelogram.
-RT_DEV float pair_margin(const RowEval &e) { return min_(min_(e.v, 1.0f - e.v), min_(e.u + e.v, e.w)); }
+RT_DEV float pair_margin(const RowEval &e) {
+    const float s = e.u + e.v;
+    return min_(min_(e.v, 1.0f - e.v), min_(s, 1.0f - s));
+}
 
 // A parallelogram as ONE candidate, under its first triangle's id; which of the two triangles it is
 // gets decided once, for the winner (judge_tri).  A ray that starts on one of the two cannot hit that
@@ -367,7 +378,10 @@ RT_DEV RowEval slab_eval(const SlabRow &T, const Ray &r, float inv) {
     e.thi = fma_(g, T.ct, t);
     e.tlo = fma_(-g, T.ct, t);
     e.nd_abs = abs_(da);
-    e.dead = !(e.nd_abs >= T.det_lo);
+    // Upstream's |det| cut (mesh.py:123) is left to the judge here: a row below it has |d_a| < ~1e-6,
+    // its depth is huge, and if it ever wins, the winner's re-evaluation refuses it (det_hi) and the
+    // double-precision code settles the ray.  Padding rows are never evaluated by slab_loop.
+    e.dead = false;
     return e;
 }
 
@@ -717,7 +731,7 @@ RT_DEV int ray_route(const Ray &r) {
     return (TRI == kTriBvh && len_ok) ? kRouteOpen : kRouteScan;
 }
 
-template <int TRI> struct FirstPass { typedef typename std::conditional<TRI == kTriBvh, PairBest, KeyBest>::type type; };
+template <int TRI> struct FirstPass { typedef typename std::conditional<TRI == kTriBvh, PairBest, KeyBest<TRI == kTriBrute>>::type type; };
 
 // First pass without the hierarchy walk: spheres and the linear tables.
 template <int TRI, bool HAS_SPH>
