@@ -627,3 +627,71 @@ def test_ties_and_degenerate_geometry(backend):
     with h.origin_rule():
         want2 = h.oracle_intersect(sc, o2, d2, origin_prim=g2)
     _check_hits(backend.intersect(o2, d2, origin_prim=g2), want2)
+
+
+@pytest.mark.parametrize("rotate", [False, True])
+def test_pair_rows_with_bounce_rays(backend, monkeypatch, rotate):
+    """Parallelogram rows are one candidate in the first pass and the winner's side of the diagonal is
+    decided afterwards; rows in axis-perpendicular planes use the compact table.  Bounce rays
+    (origin primitive given) that leave a wall right next to its diagonal, towards the diagonal and
+    away from it, and rays aimed at diagonals from elsewhere, must give the oracle's hits under every
+    table layout: compact rows, general parallelogram rows (the room rotated out of the axes, or the
+    compact table switched off), and plain triangle rows."""
+    import dataclasses
+
+    base = h.packed_scene("room")
+    R = np.eye(3)
+    if rotate:
+        a, b = 0.37, -0.81
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        R = Ry @ Rx
+    tv = (base.tri_verts.reshape(-1, 3) @ R.T).reshape(-1, 9)
+    sph = base.spheres.copy()
+    sph[:, :3] = sph[:, :3] @ R.T
+    aabb = base.mesh_aabb.copy()
+    for m in range(base.n_meshes):
+        pts = tv[base.mesh_tri_begin[m]:base.mesh_tri_begin[m + 1]].reshape(-1, 3)
+        aabb[m] = np.concatenate([pts.min(0), pts.max(0)])
+    sc = dataclasses.replace(base, tri_verts=np.ascontiguousarray(tv), spheres=sph, mesh_aabb=aabb)
+    rng = np.random.default_rng(23 + rotate)
+    tris = tv.reshape(-1, 3, 3)
+    o, d, g = [], [], []
+    for _ in range(12000):
+        t = int(rng.integers(0, len(tris)))
+        A, B, C = tris[t]
+        # a point of triangle t within `eps` of one of its edges (one of them is the pair's diagonal)
+        e = int(rng.integers(0, 3))
+        P, Q, S = (A, B, C) if e == 0 else ((B, C, A) if e == 1 else (C, A, B))
+        s, eps = rng.uniform(0.02, 0.98), rng.choice([0.0, 1e-7, 1e-5, 1e-3, 0.2])
+        p = P * (1 - s) + Q * s + (S - (P + Q) / 2) * eps
+        n = np.cross(B - A, C - A); n /= np.linalg.norm(n)
+        k = rng.choice([0, 1, 2])
+        if k == 0:      # grazing, across the edge
+            dd = ((P + Q) / 2 - S) * rng.uniform(0.5, 2) + n * rng.choice([-1, 1]) * rng.choice([1e-6, 1e-4, 1e-2])
+        elif k == 1:    # anywhere
+            dd = rng.normal(size=3)
+        else:           # at another triangle's edge
+            t2 = int(rng.integers(0, len(tris))); s2 = rng.uniform(0, 1); j = int(rng.integers(0, 3))
+            dd = tris[t2][j] * (1 - s2) + tris[t2][(j + 1) % 3] * s2 - p
+            if np.linalg.norm(dd) < 1e-9:
+                dd = rng.normal(size=3)
+        o.append(p); d.append(dd / np.linalg.norm(dd)); g.append(base.n_spheres + t)
+    o = np.array(o).astype(np.float32).astype(np.float64)
+    d = np.array(d).astype(np.float32).astype(np.float64)
+    g = np.array(g, np.int32)
+    with h.origin_rule():
+        want = h.oracle_intersect(sc, o, d, origin_prim=g)
+    want_free = h.oracle_intersect(sc, o, d)
+    results = {}
+    for env in (None, "RAYTRACING_AMD_NO_SLABS", "RAYTRACING_AMD_NO_QUADS"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        backend.set_scene(sc)
+        results[env] = backend.intersect(o, d, origin_prim=g)
+        free = backend.intersect(o, d)
+        if env:
+            monkeypatch.delenv(env)
+        _check_hits(results[env], want)
+        _check_hits(free, want_free)
+    assert (want["obj"] >= 0).mean() > 0.5
