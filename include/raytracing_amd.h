@@ -193,6 +193,22 @@ int rt_accum_read(rt_ctx *ctx, float *host_w_h_3);      /* blocking copy of the 
 int rt_render(rt_ctx *ctx, const rt_render_params *params, float *accum_dev, void *stream);
 int rt_synchronize(rt_ctx *ctx, void *stream);
 
+/* PostProcessing.process (src/post_processing/post_processing.py:35-82) on the device, fused into two
+ * passes over the image: exposure (:47), contrast / brightness with its clip (:56), saturation (:58-60),
+ * global Reinhard tone mapping (:62-79; key = its `a`, tone_saturation = its `saturation`) and gamma
+ * as img ** gamma (:82).  src_dev (NULL = the context's accumulation buffer) and dst_dev are
+ * (W,H,3) float32 device buffers; every source value is first multiplied by `scale` (1 /
+ * rendered_passes turns the accumulated sum into RenderResult.img_arr's values), and flip_y = 1
+ * reads row H-1-y for output row y, which is img_arr's orientation (render_result.py:46).
+ * Asynchronous on `stream`. */
+typedef struct rt_postprocess_params {
+    uint32_t struct_size;
+    float exposure, brightness, contrast, saturation, gamma;   /* PostProcessing.__init__ (:21-33) */
+    float key, tone_saturation;                                /* reinhardt_tone_mapping defaults: 0.18, 1.0 (:62-64) */
+} rt_postprocess_params;
+int rt_postprocess(rt_ctx *ctx, const float *src_dev, int32_t width, int32_t height, float scale, int32_t flip_y,
+                   const rt_postprocess_params *params, float *dst_dev, void *stream);
+
 /* Renderer.stop_render (renderer.py:149-150): later rt_render calls return RT_ERR_STOPPED until
  * rt_clear_stop. */
 int rt_request_stop(rt_ctx *ctx);

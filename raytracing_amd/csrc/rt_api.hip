@@ -20,6 +20,7 @@
 #include "rt_exact.h"
 #include "rt_filter.h"
 #include "rt_obj.h"
+#include "rt_post.h"
 #include "rt_render.h"
 #include "rt_scene.h"
 #include "rt_wavefront.h"
@@ -67,6 +68,7 @@ struct rt_ctx {
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
+    DevBuf post_partials;   // rt_postprocess: per-block reduction slots
     DevBuf wf_rays[2], wf_paths, wf_hits, wf_radiance, wf_counters, wf_partials;   // wavefront form (hierarchy scenes)
     DevBuf ray_dir, ray_res; int ray_w = 0, ray_h = 0;   // camera-ray table of the current scene at ray_w x ray_h
     std::vector<EventPair> timed;        // recorded around render launches, not yet read
@@ -1021,5 +1023,38 @@ extern "C" int rt_raytrace_batch(rt_ctx *c, int64_t n, const double *org, const 
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(rgb, b_rgb.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// post-processing (see rt_post.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" int rt_postprocess(rt_ctx *c, const float *src_dev, int32_t width, int32_t height, float scale, int32_t flip_y,
+                              const rt_postprocess_params *p, float *dst_dev, void *stream_) {
+    if (!c || !p || !dst_dev) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: NULL argument");
+    if (p->struct_size != sizeof(rt_postprocess_params)) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess_params.struct_size mismatch");
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28)) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: bad size %d x %d", width, height);
+    if (!(p->tone_saturation > 0.0f) || !(p->key > 0.0f)) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: key and tone_saturation must be positive");
+    const float *src = src_dev;
+    if (!src) {
+        if (c->acc_w != width || c->acc_h != height) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: context buffer is %dx%d, not %dx%d", c->acc_w, c->acc_h, width, height);
+        src = c->accum.as<float>();
+    }
+    if (src == dst_dev && flip_y) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: in place only without the flip");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long n = (long long)width * height;
+    const int n_blocks = (int)std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8);
+    const size_t need = (size_t)(2 * n_blocks + 2) * sizeof(double);
+    if (need > c->post_partials.bytes) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, c->post_partials.ensure(need)); }
+    PostArgs A{};
+    A.src = src; A.dst = dst_dev; A.width = width; A.height = height; A.flip_y = flip_y ? 1 : 0; A.scale = scale;
+    A.exposure = p->exposure; A.brightness = p->brightness; A.contrast = p->contrast; A.saturation = p->saturation; A.gamma = p->gamma;
+    A.key = p->key; A.tone_saturation = p->tone_saturation;
+    A.partials = c->post_partials.as<double>(); A.n_blocks = n_blocks;
+    hipLaunchKernelGGL(k_post_measure, dim3((unsigned)n_blocks), dim3(256), 0, stream, A);
+    hipLaunchKernelGGL(k_post_fold, dim3(1), dim3(64), 0, stream, A);
+    hipLaunchKernelGGL(k_post_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, A);
+    HIP_TRY(c, hipGetLastError());
     return RT_OK;
 }

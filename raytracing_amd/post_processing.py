@@ -2,8 +2,11 @@
 gamma (upstream: src/post_processing/post_processing.py:21-82).
 
 ``PostProcessing(...).process(img)`` accepts what upstream accepts (a numpy (W, H, 3) array) and,
-in addition, a torch tensor - e.g. ``RenderResult.tensor() / passes`` - in which case every stage
-runs on the tensor's device and the image never leaves HBM.  Quirks kept because they define the
+in addition, a torch tensor.  A float32 (W, H, 3) tensor on a GPU goes through the fused HIP
+kernels behind ``rt_postprocess`` (two passes over the image instead of a dozen, both global
+reductions in the first); ``process_device`` does the same straight from a renderer's accumulation
+buffer, folding in the division by the pass count and the flip to display orientation.  Other
+tensors take a stage-by-stage torch path.  Quirks kept because they define the
 output: the clip to [0, 1] happens BEFORE tone mapping (:56), the luminance weights are
 (0.299, 0.587, 0.114) (:44), Reinhard normalises by the image maximum (:72) and gamma is applied
 as ``img ** gamma``, not ``1 / gamma`` (:82).
@@ -15,6 +18,17 @@ import numpy as np
 __all__ = ["PostProcessing"]
 
 _LUMA = (0.299, 0.587, 0.114)
+_contexts: dict = {}
+
+
+def _context(device_index: int):
+    """One library context per GPU for tensors that do not come with a renderer's."""
+    be = _contexts.get(device_index)
+    if be is None:
+        from .backend.lib import HipBackend
+
+        be = _contexts[device_index] = HipBackend(device_index)
+    return be
 
 
 def _is_torch(x) -> bool:
@@ -30,7 +44,32 @@ class PostProcessing:
         self.gamma = gamma
 
     # -- public chain ---------------------------------------------------------------------------
+    def _fused(self, backend, width, height, src_ptr, scale, flip_y, device):
+        import torch
+
+        out = torch.empty((width, height, 3), dtype=torch.float32, device=device)
+        backend.postprocess(width, height, out.data_ptr(), src_ptr=src_ptr, scale=scale, flip_y=flip_y,
+                            exposure=self.exposure, brightness=self.brightness, contrast=self.contrast,
+                            saturation=self.saturation, gamma=self.gamma,
+                            stream=torch.cuda.current_stream(device).cuda_stream)
+        return out
+
+    def process_device(self, render_result):
+        """The post-processed display image (W, H, 3) of a render, as a torch tensor on the renderer's
+        GPU: ``process(render_result.img_arr)`` without the image leaving HBM."""
+        be = render_result._backend
+        if be is None or not be.accum_ptr():
+            raise RuntimeError("no device buffer: render first")
+        be.synchronize()
+        return self._fused(be, render_result.WIDTH, render_result.HEIGHT, 0, 1.0 / max(render_result.rendered_passes, 1),
+                           True, f"cuda:{be.device}")
+
     def process(self, img_arr):
+        if _is_torch(img_arr) and img_arr.is_cuda and img_arr.dim() == 3 and img_arr.shape[2] == 3:
+            import torch
+
+            x = img_arr.to(torch.float32).contiguous()
+            return self._fused(_context(x.device.index or 0), x.shape[0], x.shape[1], x.data_ptr(), 1.0, False, x.device)
         x = self.exposure_correction(img_arr)
         x = self.contrast_and_brightness_correction(x)
         x = self.saturation_correction(x)

@@ -695,3 +695,42 @@ def test_pair_rows_with_bounce_rays(backend, monkeypatch, rotate):
         _check_hits(results[env], want)
         _check_hits(free, want_free)
     assert (want["obj"] >= 0).mean() > 0.5
+
+
+def test_fused_post_processing(backend):
+    """rt_postprocess (two fused passes on the device) against upstream's own output for the same
+    image (tests/golden/postproc.npz: PostProcessing(2, 0.02, 1.1, 0.9, 1.2).process, float64) and,
+    on larger synthetic images and other settings, against the numpy statement of the chain.
+    Tolerance: 2e-5 absolute on values in [0, 1] (float32 arithmetic against float64)."""
+    import torch
+
+    from raytracing_amd import post_processing
+
+    z, _ = h.load_npz("postproc.npz")
+    pp = post_processing.PostProcessing(exposure=2, brightness=0.02, contrast=1.1, saturation=0.9, gamma=1.2)
+    dev = pp.process(torch.from_numpy(z["img"]).to("cuda:0", torch.float32))
+    assert dev.is_cuda and dev.dtype == torch.float32
+    assert np.abs(dev.cpu().numpy() - z["out"]).max() < 2e-5
+    rng = np.random.default_rng(5)
+    for (W, H), kw in (((257, 131), dict(exposure=1.0)), ((1920, 1080), dict(exposure=2, brightness=0.02, contrast=1.1)),
+                       ((3840, 2160), dict(exposure=0.7, brightness=-0.05, contrast=1.3, saturation=1.4, gamma=0.8))):
+        img = rng.gamma(0.6, 0.5, size=(W, H, 3))
+        img[rng.uniform(size=(W, H)) < 0.1] = 0.0                    # black pixels: the 1e-8 floor of the tone mapper
+        pp = post_processing.PostProcessing(**kw)
+        want = pp.process(img.astype(np.float32).astype(np.float64))
+        got = pp.process(torch.from_numpy(img).to("cuda:0", torch.float32)).cpu().numpy()
+        assert np.abs(got - want).max() < 2e-5, (W, H, np.abs(got - want).max())
+    # straight from a renderer's accumulation buffer: pass count and display flip folded in
+    sc = _set(backend, "room")
+    W, H = 96, 54
+    backend.resize(W, H)
+    backend.render(W, H, 0, 8, 6, 3)
+    backend.synchronize()
+    arr = backend.read().astype(np.float64)
+
+    class _Res:
+        WIDTH, HEIGHT, rendered_passes, _backend = W, H, 8, backend
+    pp = post_processing.PostProcessing(exposure=2, brightness=0.02, contrast=1.1)
+    got = pp.process_device(_Res()).cpu().numpy()
+    want = pp.process(arr[:, ::-1] / 8)
+    assert np.abs(got - want).max() < 2e-5
