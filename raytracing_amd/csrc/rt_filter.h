@@ -201,7 +201,7 @@ struct KeyBest {
 // primitive that is CERTAINLY hit; nothing that starts beyond it can be the closest hit or tie
 // with it, which is what lets the hierarchy walk skip boxes.
 struct PairBest {
-    static constexpr bool kPerTriangle = true;
+    static constexpr bool kPerTriangle = false;
     float lo0, lo1, tmax; int32_t id0;
     RT_DEV void init(const DevScene &) { lo0 = lo1 = tmax = kInf; id0 = -1; }
     RT_DEV void operator()(float tl, int32_t id) {

@@ -734,3 +734,63 @@ def test_fused_post_processing(backend):
     got = pp.process_device(_Res()).cpu().numpy()
     want = pp.process(arr[:, ::-1] / 8)
     assert np.abs(got - want).max() < 2e-5
+
+
+def test_empty_and_partial_scenes(backend):
+    """Edge cases of the boundary: a scene without objects (every path ends in the sky at once), a
+    scene of meshes only, of spheres only, a mesh without faces, no environment image (black,
+    scene.py:35-36), zero rays, an empty rectangle and zero samples.  Images equal the oracle's under
+    the same sample sequence (1e-4 relative)."""
+    import dataclasses
+
+    base = h.packed_scene("room")
+    e_i, e_d = np.zeros(0, np.int32), np.zeros((0, 7))
+
+    def subset(keep_meshes, keep_spheres, sky=True, extra_empty_mesh=False):
+        meshes = list(range(base.n_meshes)) if keep_meshes else []
+        tri = [base.tri_verts[base.mesh_tri_begin[m]:base.mesh_tri_begin[m + 1]] for m in meshes]
+        begin = np.concatenate([[0], np.cumsum([len(t) for t in tri])]).astype(np.int32) if meshes else np.zeros(1, np.int32)
+        aabb = base.mesh_aabb[meshes] if meshes else np.zeros((0, 6))
+        if extra_empty_mesh:
+            begin = np.concatenate([begin, begin[-1:]]).astype(np.int32)
+            aabb = np.concatenate([aabb, np.zeros((1, 6))])
+        n_mesh, n_sph = len(begin) - 1, base.n_spheres if keep_spheres else 0
+        kinds = np.array([1] * n_mesh + [0] * n_sph, np.int32)
+        index = np.array(list(range(n_mesh)) + list(range(n_sph)), np.int32)
+        mats = np.concatenate([base.materials[base.mesh_obj[meshes]] if meshes else e_d,
+                               np.tile(base.materials[:1], (1, 1)) if extra_empty_mesh else e_d,
+                               base.materials[base.sphere_obj] if keep_spheres else e_d])
+        return dataclasses.replace(
+            base, obj_kind=kinds, obj_index=index, materials=np.ascontiguousarray(mats).reshape(-1, 7),
+            spheres=base.spheres if keep_spheres else np.zeros((0, 4)),
+            sphere_obj=(np.arange(n_sph, dtype=np.int32) + n_mesh) if keep_spheres else e_i,
+            mesh_aabb=np.ascontiguousarray(aabb), mesh_obj=np.arange(n_mesh, dtype=np.int32), mesh_tri_begin=begin,
+            tri_verts=np.ascontiguousarray(np.concatenate(tri)) if meshes else np.zeros((0, 9)),
+            sky_rgb=base.sky_rgb if sky else None, object_names=["x"] * (n_mesh + n_sph))
+
+    W, H, spp, bounces = 48, 27, 3, 5
+    for name, sc in (("nothing", subset(False, False)), ("meshes only", subset(True, False)),
+                     ("spheres only", subset(False, True)), ("faceless mesh", subset(True, True, extra_empty_mesh=True)),
+                     ("no sky", subset(True, True, sky=False))):
+        backend.set_scene(sc)
+        backend.resize(W, H)
+        backend.render(W, H, 0, spp, bounces, h.SEED_RENDER)
+        backend.synchronize()
+        img = backend.read().astype(np.float64)
+        with h.origin_rule():
+            ref, rays = h.oracle_render(sc, W, H, spp, bounces)
+        off = np.abs(img - ref).max(axis=2) > 1e-4 * (1.0 + ref.max(axis=2))
+        assert np.isfinite(img).all() and off.mean() < 0.02, (name, int(off.sum()))
+        if name == "nothing":
+            assert backend.stats()["rays"] >= W * H * spp and not off.any() and img.min() > 0
+        if name == "no sky":
+            assert (img.max(axis=2) == 0).mean() > 0.01           # escaping paths bring nothing home
+        # no rays, an empty rectangle, no samples: accepted, nothing changes
+        before = backend.read()
+        out = backend.intersect(np.zeros((0, 3)), np.zeros((0, 3)))
+        assert out["obj"].shape == (0,)
+        backend.render(W, H, 0, spp, bounces, 1, rect=(5, 5, 0, H))
+        backend.render(W, H, 0, 0, bounces, 1)
+        backend.synchronize()
+        assert np.array_equal(before, backend.read())
+        assert backend.raytrace(np.zeros((0, 3)), np.zeros((0, 3)), bounces).shape == (0, 3)
