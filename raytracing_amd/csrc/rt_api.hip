@@ -590,7 +590,8 @@ struct IsectArgs {
 };
 
 template <int TRI, bool HAS_SPH>
-__global__ __launch_bounds__(256) void k_intersect(const DevScene S, const IsectArgs A) {
+__global__ __launch_bounds__(256) void k_intersect(const DevScene S_arg, const IsectArgs A) {
+    SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
     const double ox = A.org[3 * i], oy = A.org[3 * i + 1], oz = A.org[3 * i + 2];

@@ -111,7 +111,7 @@ RT_DEV double exact_tri_depth(const double *tv, D3 o, D3 d) {
 struct ScanHit { int32_t gprim; double t; };   // gprim < 0: miss
 
 // One primitive by global id, with its mesh's bounding-box gate.
-RT_DEV ExactHit exact_single(const DevScene &S, int32_t gprim, D3 o, D3 d, int32_t origin) {
+RT_DEV ExactHit exact_single(SceneRef S, int32_t gprim, D3 o, D3 d, int32_t origin) {
     const ColdScene &C = *S.cold;
     if (gprim < S.n_spheres) return exact_sphere(C.sph64 + 4 * (size_t)gprim, o, d, gprim == origin);
     int32_t ti = gprim - S.n_spheres;
@@ -125,7 +125,7 @@ RT_DEV ExactHit exact_single(const DevScene &S, int32_t gprim, D3 o, D3 d, int32
 // hit = false when upstream would not report it.
 struct ExactDepth { bool hit; double t; };
 
-RT_DEV ExactDepth exact_single_depth(const DevScene &S, int32_t gprim, D3 o, D3 d, int32_t origin) {
+RT_DEV ExactDepth exact_single_depth(SceneRef S, int32_t gprim, D3 o, D3 d, int32_t origin) {
     const ColdScene &C = *S.cold;
     ExactDepth r; r.hit = false; r.t = 0;
     ExactHit h;
@@ -143,7 +143,7 @@ RT_DEV ExactDepth exact_single_depth(const DevScene &S, int32_t gprim, D3 o, D3 
 // Scene.intersect(ray)[0]: first minimum of depth in object order, then per-object hit order.
 // Returns the identity and depth only; the caller re-evaluates the winner for position / normal
 // (same arithmetic, so the same depth).
-RT_DEV ScanHit exact_scan(const DevScene &S, D3 o, D3 d, int32_t origin) {
+RT_DEV ScanHit exact_scan(SceneRef S, D3 o, D3 d, int32_t origin) {
     const ColdScene &C = *S.cold;
     ScanHit best; best.gprim = -1; best.t = __builtin_inf();
     for (int oi = 0; oi < C.n_objects; ++oi) {

@@ -114,7 +114,7 @@ struct Ray {
 
 // `rounded` = the ray is the float32 rounding of a double-precision ray the exact code will use
 // (camera rays): every bound then also covers u per component of o and d.
-RT_DEV Ray make_ray(const DevScene &S, float ox, float oy, float oz, float dx, float dy, float dz, int32_t origin,
+RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy, float dz, int32_t origin,
                     bool rounded) {
     Ray r;
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
@@ -175,7 +175,7 @@ template <bool VECTOR_MASK>
 struct KeyBest {
     static constexpr bool kPerTriangle = false;   // a parallelogram row is ONE candidate (its first triangle's id)
     uint32_t k0, k1, keep_mask, id_mask;
-    RT_DEV void init(const DevScene &S) {
+    RT_DEV void init(SceneRef S) {
         k0 = k1 = 0xFFFFFFFFu; id_mask = S.key_mask;
         // the mask lives in a VECTOR register: (bits & mask) | id is then one v_and_or_b32 with the row's id
         // as its single scalar operand (two scalar operands would need a second instruction per row)
@@ -203,7 +203,7 @@ struct KeyBest {
 struct PairBest {
     static constexpr bool kPerTriangle = false;
     float lo0, lo1, tmax; int32_t id0;
-    RT_DEV void init(const DevScene &) { lo0 = lo1 = tmax = kInf; id0 = -1; }
+    RT_DEV void init(SceneRef) { lo0 = lo1 = tmax = kInf; id0 = -1; }
     RT_DEV void operator()(float tl, int32_t id) {
         const bool better = tl < lo0;
         lo1 = better ? lo0 : min_(lo1, tl);
@@ -218,7 +218,7 @@ struct PairBest {
     RT_DEV void certain_hit(float thi) { tmax = min_(tmax, thi); }
 };
 
-RT_DEV uint64_t scene_order(const DevScene &S, int32_t gprim) {
+RT_DEV uint64_t scene_order(SceneRef S, int32_t gprim) {
     const int32_t obj = gprim < S.n_spheres ? S.sph_obj[gprim] : S.tri_aux[gprim - S.n_spheres].obj;
     return ((uint64_t)(uint32_t)obj << 32) | (uint32_t)gprim;
 }
@@ -231,7 +231,7 @@ RT_DEV uint64_t scene_order(const DevScene &S, int32_t gprim) {
 // `limit` has a true depth beyond a proven hit and cannot win or tie.
 struct Resolve {
     static constexpr bool kPerTriangle = true;
-    const DevScene *S;
+    ScenePtr S;
     D3 o, d;
     int32_t origin, skip;      // skip: the first-pass winner, already evaluated
     float limit;
@@ -402,7 +402,7 @@ RT_DEV void slab_loop(const SlabRow *rows, int begin, int n, const Ray &r, Sink 
 // tail and may read one trip ahead: a row's scalar load is issued a full test (~40 vector
 // instructions) before the row is used.
 template <class Sink>
-RT_DEV void search_tris(const DevScene &S, const Ray &r, Sink &sink) {
+RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
     if (S.n_quad_rows_padded > 0) {
         // one candidate per parallelogram: only the rows in general position; the rest follow in compact form
         const int n = Sink::kPerTriangle ? S.n_quad_rows_padded : S.n_quad_general;
@@ -473,7 +473,7 @@ RT_DEV BvhCounters bvh_counters() { BvhCounters b; b.nodes = 0; b.tris = 0; b.to
 // slices so that lanes whose rays finish early can take new work instead of idling until the
 // slowest ray of the wave (one that grazes a dense mesh visits ten times the average) is through.
 template <class Sink>
-RT_DEV void search_bvh(const DevScene &S, const Ray &r, Sink &sink, BvhCounters &bc, int &node, int budget) {
+RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, int &node, int budget) {
     const float ix = rcp_(r.dx), iy = rcp_(r.dy), iz = rcp_(r.dz);
     const float pad = 10.0f * kU * (r.o2 + S.scene_radius);
     const float oxp = r.ox + pad, oyp = r.oy + pad, ozp = r.oz + pad;   // subtracted from the low planes
@@ -530,7 +530,7 @@ struct Verdict { int status; float t, thi; int32_t ti; bool open; };
 // the error band of the diagonal leaves it open (Verdict::open: both go to the double-precision
 // tie-break, scene.py:24-27).
 template <bool PAIRS>
-RT_DEV Verdict judge_tri(const DevScene &S, int32_t ti, const Ray &r, float rel_accept, float abs_accept) {
+RT_DEV Verdict judge_tri(SceneRef S, int32_t ti, const Ray &r, float rel_accept, float abs_accept) {
     const TriAux X = S.tri_aux[ti];
     const bool pair = PAIRS && X.pair_row >= 0;
     const TriRow T = pair ? S.quad_rows[X.pair_row] : S.tri_by_id[ti];
@@ -587,7 +587,7 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
 }
 
 template <class Sink>
-RT_DEV void search_spheres(const DevScene &S, const Ray &r, Sink &sink) {
+RT_DEV void search_spheres(SceneRef S, const Ray &r, Sink &sink) {
     const int n = S.n_sph_rows;
     const SphRow *rows = S.sph_rows;
 #pragma unroll 2
@@ -621,7 +621,7 @@ RT_DEV void search_spheres(const DevScene &S, const Ray &r, Sink &sink) {
 
 // The few huge spheres: double precision throughout.
 template <class Sink>
-RT_DEV void search_big_spheres(const DevScene &S, const Ray &r, D3 o64, D3 d64, Sink &sink) {
+RT_DEV void search_big_spheres(SceneRef S, const Ray &r, D3 o64, D3 d64, Sink &sink) {
     for (int i = 0; i < S.n_big_sph; ++i) {
         int si = S.big_sph[i];
         ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
@@ -632,7 +632,7 @@ RT_DEV void search_big_spheres(const DevScene &S, const Ray &r, D3 o64, D3 d64, 
 
 struct SphVerdict { int status; int root; float t, thi; };
 
-RT_DEV SphVerdict judge_sphere(const DevScene &S, int32_t si, const Ray &r, float rel_accept, float abs_accept) {
+RT_DEV SphVerdict judge_sphere(SceneRef S, int32_t si, const Ray &r, float rel_accept, float abs_accept) {
     const SphRow P = S.sph_by_id[si];
     SphBounds o = sphere_bounds(P, r);
     SphVerdict v; v.status = 2; v.root = 0; v.t = 0; v.thi = 0;
@@ -684,7 +684,7 @@ RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r
 enum { kTriNone = 0, kTriBrute = 1, kTriBvh = 2 };
 
 template <int TRI, bool HAS_SPH, class Sink>
-RT_DEV void search_all(const DevScene &S, const Ray &r, D3 o64, D3 d64, Sink &sink, BvhCounters &bc) {
+RT_DEV void search_all(SceneRef S, const Ray &r, D3 o64, D3 d64, Sink &sink, BvhCounters &bc) {
     if (HAS_SPH) {
         search_spheres(S, r, sink);
         search_big_spheres(S, r, o64, d64, sink);
@@ -693,7 +693,7 @@ RT_DEV void search_all(const DevScene &S, const Ray &r, D3 o64, D3 d64, Sink &si
     if (TRI == kTriBvh) { int node = 0; search_bvh(S, r, sink, bc, node, 0x7FFFFFFF); }
 }
 
-RT_DEV void exact_scan_pass(const DevScene &S, D3 o64, D3 d64, int32_t origin, ExactHit &e, int32_t &gprim) {
+RT_DEV void exact_scan_pass(SceneRef S, D3 o64, D3 d64, int32_t origin, ExactHit &e, int32_t &gprim) {
     ScanHit sh = exact_scan(S, o64, d64, origin);
     gprim = sh.gprim;
     e.hit = false;
@@ -735,7 +735,7 @@ template <int TRI> struct FirstPass { typedef typename std::conditional<TRI == k
 
 // First pass without the hierarchy walk: spheres and the linear tables.
 template <int TRI, bool HAS_SPH>
-RT_DEV void hit_begin(const DevScene &S, const Ray &r, const RayResidue rr, typename FirstPass<TRI>::type &first) {
+RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename FirstPass<TRI>::type &first) {
     first.init(S);
     if (HAS_SPH) {
         search_spheres(S, r, first);
@@ -751,7 +751,7 @@ RT_DEV void hit_begin(const DevScene &S, const Ray &r, const RayResidue rr, type
 // record.  `e64`, when given, receives the double-precision record whenever the exact code produced
 // the hit (e64->hit says whether it did).
 template <int TRI, bool HAS_SPH, bool STRICT>
-RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
+RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
                       BvhCounters bc, ExactHit *e64) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
     h.refined = false; h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
@@ -867,7 +867,7 @@ RT_DEV Hit hit_finish(const DevScene &S, const Ray &r, const RayResidue rr, cons
 
 // One closest-hit query from start to end.
 template <int TRI, bool HAS_SPH, bool STRICT>
-RT_DEV Hit closest_hit(const DevScene &S, const Ray &r, ExactHit *e64, const RayResidue rr) {
+RT_DEV Hit closest_hit(SceneRef S, const Ray &r, ExactHit *e64, const RayResidue rr) {
     typename FirstPass<TRI>::type first;
     first.init(S);
     BvhCounters bc = bvh_counters();

@@ -93,7 +93,7 @@ RT_DEV float asin_over_pi(float x) {
     return x < 0.0f ? -r : r;
 }
 
-RT_DEV void environment(const DevScene &S, float dx, float dy, float dz, float &r, float &g, float &b) {
+RT_DEV void environment(SceneRef S, float dx, float dy, float dz, float &r, float &g, float &b) {
     if (S.sky == nullptr) { r = g = b = 0.0f; return; }
     float y = min_(max_(dy, -1.0f), 1.0f);
     float u = 0.5f + atan2_turns(dz, dx);
@@ -120,7 +120,8 @@ RT_DEV double rsqrt64(double x) {
 // divisions included, so the doubles are bit-identical to upstream's.  Writes, per pixel
 // (x * H + y), the float32 direction and the residue double - float32.  Runs once per
 // (camera, W, H); the render kernel only loads from the table.
-__global__ __launch_bounds__(256) void k_raygen(const DevScene S, int W, int H, float *ray_dir, float *ray_res) {
+__global__ __launch_bounds__(256) void k_raygen(const DevScene S_arg, int W, int H, float *ray_dir, float *ray_res) {
+    SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W * H) return;
     const int x = i / H, y = i - x * H;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene S, int W, int H, 
 // aperture offset and the re-aimed direction are worked out here from this path's two draws, in
 // double precision with a Newton reciprocal square root (~1e-16 of upstream's doubles), and the
 // float32 rounding of that ray is THE ray (no residue: the jitter decorrelates edge cases anyway).
-RT_DEV void camera_ray(const DevScene &S, const float *ray_dir, const float *ray_res, uint32_t pixel, uint32_t key0,
+RT_DEV void camera_ray(SceneRef S, const float *ray_dir, const float *ray_res, uint32_t pixel, uint32_t key0,
                        uint32_t key1, float &ox, float &oy, float &oz, float &dx, float &dy, float &dz) {
     const f4 q = *(const f4 *)(ray_dir + 4 * (size_t)pixel);
     dx = q.x; dy = q.y; dz = q.z;
@@ -216,7 +217,7 @@ struct Path {
     uint32_t pixel;                 // x * H + y: Philox key and row of the camera-ray table
 };
 
-RT_DEV void path_begin(const DevScene &S, const float *ray_dir, const float *ray_res, Path &p, uint32_t pixel,
+RT_DEV void path_begin(SceneRef S, const float *ray_dir, const float *ray_res, Path &p, uint32_t pixel,
                        uint32_t sample, uint32_t seed_lo, uint32_t seed_hi) {
     p.key0 = pixel ^ seed_lo; p.key1 = sample ^ seed_hi;
     camera_ray(S, ray_dir, ray_res, pixel, p.key0, p.key1, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz);
@@ -225,7 +226,7 @@ RT_DEV void path_begin(const DevScene &S, const float *ray_dir, const float *ray
 }
 
 
-RT_DEV RayResidue path_residue(const DevScene &S, const float *ray_res, const Path &p) {
+RT_DEV RayResidue path_residue(SceneRef S, const float *ray_res, const Path &p) {
     // a pinhole camera ray is the rounding of a double-precision ray whose residue is in the table
     RayResidue rr;
     rr.table = ray_res; rr.pixel = p.pixel; rr.on = (p.depth == 0) && !S.dof_on;
@@ -235,7 +236,7 @@ RT_DEV RayResidue path_residue(const DevScene &S, const float *ray_res, const Pa
 
 // What follows a closest-hit answer: environment or one bounce.  Returns true while the path goes
 // on; when it returns false (er, eg, eb) is the terminal radiance to be multiplied by (tr, tg, tb).
-RT_DEV bool path_shade(const DevScene &S, Path &p, int max_bounces, const Hit &h, float &er, float &eg, float &eb) {
+RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float &er, float &eg, float &eb) {
     er = eg = eb = 0.0f;
     if (h.obj < 0) {
         environment(S, p.dx, p.dy, p.dz, er, eg, eb);
@@ -252,7 +253,7 @@ RT_DEV bool path_shade(const DevScene &S, Path &p, int max_bounces, const Hit &h
 
 // One segment: closest hit, then environment or one bounce.
 template <int TRI, bool HAS_SPH>
-RT_DEV bool path_step(const DevScene &S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h) {
+RT_DEV bool path_step(SceneRef S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h) {
     Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0);
     h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, path_residue(S, ray_res, p));
     return path_shade(S, p, max_bounces, h, er, eg, eb);
@@ -285,7 +286,8 @@ constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at
 constexpr int kWalkSlice = 8;   // boxes a lane visits per trip of the render loop (hierarchy scenes)
 
 template <int TRI, bool HAS_SPH>
-__global__ __launch_bounds__(256, TRI == kTriBvh ? 3 : 4) void k_render(const DevScene S, const RenderArgs A) {
+__global__ __launch_bounds__(256, TRI == kTriBvh ? 3 : 4) void k_render(const DevScene S_arg, const RenderArgs A) {
+    SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     // wave-uniform job window
     uint32_t win_next = 0, win_end = 0;
     bool drained = false;
@@ -318,11 +320,14 @@ __global__ __launch_bounds__(256, TRI == kTriBvh ? 3 : 4) void k_render(const De
     int walk_node = -1;
     bool walking = false;
     KernargRenderArgs J = kernarg_render_args();
+    ScenePtr Sp = kernarg_scene();
     // (spheres-only kernels measured 2 % faster with the plain by-value arguments)
 #define JOB(member) (TRI != kTriNone ? J->member : A.member)
 
     for (;;) {
         asm volatile("" : "+s"(J));
+        if (TRI != kTriNone) asm volatile("" : "+s"(Sp));   // (spheres-only kernels measured faster without)
+        SceneRef S = *Sp;   // (shadows the launch-wide binding: this trip's reads start here)
         // ---- 1. hand jobs to idle lanes ------------------------------------------------------
         unsigned long long idle = __ballot(!have_job);
         while (idle != 0 && !(drained && win_next == win_end)) {
@@ -467,7 +472,8 @@ struct TraceArgs {
 };
 
 template <int TRI, bool HAS_SPH>
-__global__ __launch_bounds__(256) void k_trace_paths(const DevScene S, const TraceArgs A) {
+__global__ __launch_bounds__(256) void k_trace_paths(const DevScene S_arg, const TraceArgs A) {
+    SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n_paths) return;
     const int x = A.xys[3 * i], y = A.xys[3 * i + 1], smp = A.xys[3 * i + 2];
@@ -506,7 +512,8 @@ struct RaytraceArgs {
 };
 
 template <int TRI, bool HAS_SPH>
-__global__ __launch_bounds__(256) void k_raytrace(const DevScene S, const RaytraceArgs A) {
+__global__ __launch_bounds__(256) void k_raytrace(const DevScene S_arg, const RaytraceArgs A) {
+    SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long rays = 0, sky = 0, shaded = 0, paths = 0;
     if (i < A.n) {

@@ -113,6 +113,17 @@ struct DevScene {
     const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale;
 };
 
+// Device code reads the scene where the launch put it: the kernel-argument block, which is constant
+// memory.  A member read through this reference is a scalar load at the point of use, not a scalar
+// register held for the whole launch (DevScene is ~55 dwords; held in registers they push other
+// scalars into vector-register lanes, and every v_readlane that brings one back is a vector
+// instruction).  Every kernel takes the scene as its FIRST by-value argument, so it sits at offset 0.
+typedef const DevScene __attribute__((address_space(4))) &SceneRef;
+typedef const DevScene __attribute__((address_space(4))) *ScenePtr;
+#if defined(__HIPCC__)
+__device__ __forceinline__ ScenePtr kernarg_scene() { return (ScenePtr)__builtin_amdgcn_kernarg_segment_ptr(); }
+#endif
+
 // Division of a 32-bit unsigned by a launch-invariant divisor (Granlund & Montgomery): the host fills
 // the constants, the device spends a multiply-high and two shifts instead of a ~30-instruction divide.
 struct FastDiv { uint32_t d, m, sh1, sh2; };

@@ -70,7 +70,8 @@ RT_DEV void wf_path_coords(const WfArgs &A, uint32_t p, uint32_t &pixel, uint32_
     sample = (uint32_t)A.sample_begin + j;
 }
 
-__global__ __launch_bounds__(256) void k_wf_generate(const DevScene S, const WfArgs A) {
+__global__ __launch_bounds__(256) void k_wf_generate(const DevScene S_arg, const WfArgs A) {
+    SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.n_paths) return;
     uint32_t pixel, sample;
@@ -89,7 +90,8 @@ constexpr int kWfGrab = 256;    // rays a wave reserves from the queue at a time
                                  // same-address atomics complete at only ~0.1 G/s)
 
 template <bool HAS_SPH>
-__global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S, const WfArgs A) {
+__global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, const WfArgs A) {
+    SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     constexpr int TRI = kTriBvh;
     const uint32_t total = *A.count_in;
     uint32_t win_next = 0, win_end = 0;
@@ -177,7 +179,8 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S, const Wf
     }
 }
 
-__global__ __launch_bounds__(256) void k_wf_shade(const DevScene S, const WfArgs A) {
+__global__ __launch_bounds__(256) void k_wf_shade(const DevScene S_arg, const WfArgs A) {
+    SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = *A.count_in;
     const bool live = i < total;
