@@ -286,7 +286,7 @@ constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at
 constexpr int kWalkSlice = 8;   // boxes a lane visits per trip of the render loop (hierarchy scenes)
 
 template <int TRI, bool HAS_SPH>
-__global__ __launch_bounds__(256, TRI == kTriBvh ? 3 : 4) void k_render(const DevScene S_arg, const RenderArgs A) {
+__global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const RenderArgs A) {
     SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     // wave-uniform job window
     uint32_t win_next = 0, win_end = 0;
