@@ -267,6 +267,25 @@ def test_error_reporting(backend):
     fresh.clear_stop()
     fresh.render(64, 64, 0, 1, 4, 0)
     fresh.synchronize()
+    # the other entry points refuse bad requests the same way: status + message, nothing thrown across
+    import torch
+    out = torch.empty((64, 64, 3), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(BackendError) as e:
+        fresh.postprocess(32, 32, out.data_ptr())                     # context buffer is 64 x 64
+    assert e.value.status == 1 and "64x64" in str(e.value)
+    with pytest.raises(BackendError):
+        fresh.postprocess(64, 64, out.data_ptr(), tone_saturation=0.0)
+    with pytest.raises(BackendError):
+        fresh.postprocess(64, 64, fresh.accum_ptr(), src_ptr=fresh.accum_ptr(), flip_y=True)   # in place needs no flip
+    with pytest.raises(BackendError):
+        fresh.raytrace(np.zeros((1, 3)), np.ones((1, 3)), 63)         # at most 62 bounces
+    with pytest.raises(ValueError):
+        fresh.raytrace(np.zeros((2, 3)), np.ones((1, 3)), 4)
+    empty = HipBackend(0)
+    with pytest.raises(BackendError) as e:
+        empty.raytrace(np.zeros((1, 3)), np.ones((1, 3)), 4)
+    assert e.value.status == 2
+    empty.close()
     fresh.close()
 
 
