@@ -813,3 +813,74 @@ def test_empty_and_partial_scenes(backend):
         backend.synchronize()
         assert np.array_equal(before, backend.read())
         assert backend.raytrace(np.zeros((0, 3)), np.zeros((0, 3)), bounces).shape == (0, 3)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_soup_of_every_row_kind(backend, seed):
+    """One scene holding every kind of table row at once - lone triangles, parallelograms in general
+    position, parallelograms in axis-perpendicular planes on all three axes, small spheres, one huge
+    sphere - in several meshes with overlaps and interpenetration; free rays and bounce rays (origin
+    primitive given) against the oracle, hit identity exact."""
+    import dataclasses
+
+    base = h.packed_scene("room")
+    rng = np.random.default_rng(100 + seed)
+    meshes = []
+    tris = []
+    for _ in range(150):                                        # lone triangles
+        c = rng.uniform(-1, 1, 3)
+        tris.append(np.concatenate([c + rng.normal(scale=0.3, size=3) for _ in range(3)]))
+    meshes.append(np.array(tris))
+    quads = []
+    for _ in range(25):                                         # parallelograms in general position
+        a = rng.uniform(-1, 1, 3); e1 = rng.normal(scale=0.4, size=3); e2 = rng.normal(scale=0.4, size=3)
+        b, c, d = a + e1, a + e1 + e2, a + e2
+        quads += [np.concatenate([a, b, c]), np.concatenate([a, c, d])] if rng.uniform() < 0.5 else \
+                 [np.concatenate([b, c, a]), np.concatenate([d, a, c])]
+    meshes.append(np.array(quads))
+    slabs = []
+    for k in range(18):                                         # axis-perpendicular rectangles and parallelograms
+        axis = k % 3
+        b_ax, c_ax = [i for i in range(3) if i != axis]
+        a = rng.uniform(-1, 1, 3)
+        e1, e2 = np.zeros(3), np.zeros(3)
+        e1[b_ax] = rng.uniform(0.2, 0.8); e2[c_ax] = rng.uniform(0.2, 0.8)
+        if k % 2:
+            e2[b_ax] = rng.uniform(-0.3, 0.3)                   # sheared: edges not along the axes
+        b, c, d = a + e1, a + e1 + e2, a + e2
+        slabs += [np.concatenate([a, b, c]), np.concatenate([a, c, d])]
+    meshes.append(np.array(slabs))
+    tv = np.concatenate(meshes)
+    begin = np.concatenate([[0], np.cumsum([len(m) for m in meshes])]).astype(np.int32)
+    aabb = np.array([np.concatenate([m.reshape(-1, 3).min(0), m.reshape(-1, 3).max(0)]) for m in meshes])
+    n_mesh = len(meshes)
+    sph = np.concatenate([np.concatenate([rng.uniform(-1, 1, (20, 3)), rng.uniform(0.05, 0.3, (20, 1))], axis=1),
+                          [[0.0, -1001.5, 0.0, 1000.0]]])
+    n_sph = len(sph)
+    kinds = np.array([1] * n_mesh + [0] * n_sph, np.int32)
+    index = np.array(list(range(n_mesh)) + list(range(n_sph)), np.int32)
+    mats = np.tile(base.materials[:1], (n_mesh + n_sph, 1))
+    sc = dataclasses.replace(base, obj_kind=kinds, obj_index=index, materials=np.ascontiguousarray(mats),
+                             spheres=np.ascontiguousarray(sph), sphere_obj=np.arange(n_sph, dtype=np.int32) + n_mesh,
+                             mesh_aabb=np.ascontiguousarray(aabb), mesh_obj=np.arange(n_mesh, dtype=np.int32),
+                             mesh_tri_begin=begin, tri_verts=np.ascontiguousarray(tv), object_names=["x"] * (n_mesh + n_sph))
+    backend.set_scene(sc)
+    n = 40000
+    o = rng.uniform(-1.3, 1.3, (n, 3)).astype(np.float32).astype(np.float64)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    want = h.oracle_intersect(sc, o, d)
+    _check_hits(backend.intersect(o, d), want)
+    hit = want["obj"] >= 0
+    assert hit.mean() > 0.5 and len(set(want["obj"][hit])) > 10
+    o2 = want["pos"][hit].astype(np.float32).astype(np.float64)
+    g2 = want["gprim"][hit].astype(np.int32)
+    d2 = rng.normal(size=o2.shape)
+    d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+    with h.origin_rule():
+        want2 = h.oracle_intersect(sc, o2, d2, origin_prim=g2)
+    _check_hits(backend.intersect(o2, d2, origin_prim=g2), want2)
+    # the same scene through a hierarchy built by the library
+    backend.set_scene(dataclasses.replace(sc, library_bvh=True))
+    _check_hits(backend.intersect(o, d), want)
+    _check_hits(backend.intersect(o2, d2, origin_prim=g2), want2)
