@@ -485,13 +485,16 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
     const TriRow *rows = S.leaf_rows;
     if (S.n_bvh_nodes <= 0) node = -1;
     int visited = 0;
-    // Two nested loops ("while-while"): every lane first walks boxes until it stands on a leaf, then
-    // the lanes test their leaves' triangles together.  With a single loop the few lanes that are on
-    // a leaf at any moment would make the whole wave run the triangle code on every trip.
-    while (visited < budget) {
+    // Each trip of the outer loop is a sub-slice: every lane walks boxes until it has found a leaf (it
+    // then goes on - the leaf waits), stands before a second one, or has used the sub-slice up; then
+    // all lanes that hold a leaf test its triangles TOGETHER.  Testing a leaf the moment a lane finds
+    // it would run the triangle code for that one lane while the others wait ("while-while" loops
+    // still did that three or four times per slice).
+    constexpr int kSubSlice = 4;   // measured on 310 ... 1.18 M triangles: 2 / 4 / 8 -> 4.58 / 4.84 / 4.72 G rays/s at 1.18 M
+    while (visited < budget && node >= 0) {
+        const int stop = visited + kSubSlice < budget ? visited + kSubSlice : budget;
         int32_t leaf = -1;
-        while (node >= 0 && visited < budget) {
-            ++visited;
+        while (node >= 0 && visited < stop) {
             f4 a, b;
             if (node < bc.n_top) { a = top[2 * node]; b = top[2 * node + 1]; }                // top levels: LDS
             else { a = nodes[2 * (size_t)node]; b = nodes[2 * (size_t)node + 1]; }
@@ -502,21 +505,28 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
             const float z0 = (a.z - ozp) * iz, z1 = (b.z - ozm) * iz;
             const float tn = max_(max_(min_(x0, x1), min_(y0, y1)), max_(min_(z0, z1), 0.0f));
             const float tf = min_(min_(max_(x0, x1), max_(y0, y1)), min_(max_(z0, z1), sink.prune_bound()));
-            bc.nodes++;
             const bool hit = tn <= tf;
-            if (hit && info >= 0) { leaf = info; node = skip; break; }
-            node = hit ? (info == -1 ? node + 1 : -info - 2) : skip;   // inner node: first child, given or next
+            if (hit && info >= 0) {
+                if (leaf >= 0) break;        // a second leaf: it is met again (and counted) next time round
+                leaf = info; node = skip;
+            } else {
+                node = hit ? (info == -1 ? node + 1 : -info - 2) : skip;   // inner node: first child, given or next
+            }
+            ++visited;
+            bc.nodes++;
         }
-        if (leaf < 0) break;
-        const int first = leaf >> 4, cnt = leaf & 15;
-        bc.tris += (uint32_t)cnt;
-        for (int k = 0; k < cnt; ++k) {
-            const TriRow cur = load_tri_row_lane(rows, first + k);
-            float sure_thi;
-            const float tl = tri_tlo<true>(cur, r, &sure_thi);
-            sink.certain_hit(sure_thi);
-            sink(tl, cur.gprim);
+        if (leaf >= 0) {
+            const int first = leaf >> 4, cnt = leaf & 15;
+            bc.tris += (uint32_t)cnt;
+            for (int k = 0; k < cnt; ++k) {
+                const TriRow cur = load_tri_row_lane(rows, first + k);
+                float sure_thi;
+                const float tl = tri_tlo<true>(cur, r, &sure_thi);
+                sink.certain_hit(sure_thi);
+                sink(tl, cur.gprim);
+            }
         }
+        // a lane that stopped before a second leaf has budget left: it goes round again
     }
 }
 

@@ -216,7 +216,7 @@ def test_progressive_batches_and_device_tonemap(backend):
 def test_wavefront_form_traces_the_same_paths(backend, monkeypatch):
     """The optional wavefront form (generate / extend / shade / resolve kernels) runs the same device
     functions as the single render kernel, so images agree up to float32 summation order and the
-    statistics are identical."""
+    statistics agree (test counts of the walk to within a percent)."""
     base = h.packed_scene("room_horse")
     backend.set_scene(base.with_subdivided_mesh(base.n_meshes - 1, 3))
     W, H, spp, b = 96, 54, 6, 5
@@ -234,5 +234,10 @@ def test_wavefront_form_traces_the_same_paths(backend, monkeypatch):
     monkeypatch.delenv("RAYTRACING_AMD_WF_PATHS")
     (a, sa), (w, sw) = out
     assert np.allclose(a, w, rtol=1e-5, atol=1e-6), np.abs(a - w).max()
-    for k in ("rays", "paths", "tri_tests", "sphere_tests", "bvh_node_tests", "exact_rays", "refined_hits", "sky_lookups", "shaded_hits"):
+    for k in ("rays", "paths", "sphere_tests", "exact_rays", "refined_hits", "sky_lookups", "shaded_hits"):
         assert sa[k] == sw[k], (k, sa[k], sw[k])
+    # how many boxes and leaf triangles a walk tests depends a little on where its slices end (a leaf
+    # met at the end of a slice is tested before or after the boxes that follow it, which moves the
+    # pruning bound): the two forms cut their walks differently
+    for k in ("tri_tests", "bvh_node_tests"):
+        assert abs(sa[k] - sw[k]) <= 0.01 * sa[k], (k, sa[k], sw[k])
