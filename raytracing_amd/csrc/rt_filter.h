@@ -642,9 +642,7 @@ RT_DEV void search_big_spheres(SceneRef S, const Ray &r, D3 o64, D3 d64, Sink &s
 
 struct SphVerdict { int status; int root; float t, thi; };
 
-RT_DEV SphVerdict judge_sphere(SceneRef S, int32_t si, const Ray &r, float rel_accept, float abs_accept) {
-    const SphRow P = S.sph_by_id[si];
-    SphBounds o = sphere_bounds(P, r);
+RT_DEV SphVerdict sphere_verdict(const SphRow &P, const SphBounds &o, int32_t si, const Ray &r, float rel_accept, float abs_accept) {
     SphVerdict v; v.status = 2; v.root = 0; v.t = 0; v.thi = 0;
     float lo, hi, t; int root; bool certain;
     if (si == r.origin) {
@@ -664,6 +662,35 @@ RT_DEV SphVerdict judge_sphere(SceneRef S, int32_t si, const Ray &r, float rel_a
     bool precise = (half <= max_(rel_accept * t, abs_accept)) && (perr <= rel_accept * P.r);
     v.status = precise ? 0 : 1;
     return v;
+}
+
+RT_DEV SphVerdict judge_sphere(SceneRef S, int32_t si, const Ray &r, float rel_accept, float abs_accept) {
+    const SphRow P = S.sph_by_id[si];
+    return sphere_verdict(P, sphere_bounds(P, r), si, r, rel_accept, abs_accept);
+}
+
+// Scenes with one or two small spheres: the search loop's cheap discriminant test followed by the
+// winner's precise re-evaluation would evaluate the same sphere twice for every ray that comes near
+// it.  Such scenes get the precise bounds at once, in the first pass, and the verdict of the
+// nearest sphere candidate is kept for hit_finish (SpherePre::id says whose it is).
+constexpr int kFewSpheres = 2;
+struct SpherePre { int32_t id; float tl; SphVerdict v; };
+
+template <class Sink>
+RT_DEV void search_few_spheres(SceneRef S, const Ray &r, Sink &sink, SpherePre &pre, float rel_accept, float abs_accept) {
+    const int n = S.n_sph_rows;
+    const SphRow *rows = S.sph_rows;
+    for (int i = 0; i < n; ++i) {
+        const SphRow P = load_sph_row_uniform(rows, i);
+        const SphBounds o = sphere_bounds(P, r);
+        const bool own = P.gprim == r.origin;
+        // candidate exactly when the cheap test would have one: possibly touched, and the root that counts may lie ahead
+        const bool valid = o.maybe && (own ? (o.b < o.eb) : (o.t2hi > 0.0f));
+        float tl = own ? o.t2lo : (o.t1hi < 0.0f ? o.t2lo : o.t1lo);
+        tl = valid ? max_(tl, 0.0f) * (1.0f - 8.0f * kU) : kInf;
+        sink(tl, P.gprim);
+        if (tl < pre.tl) { pre.tl = tl; pre.id = P.gprim; pre.v = sphere_verdict(P, o, P.gprim, r, rel_accept, abs_accept); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -745,10 +772,12 @@ template <int TRI> struct FirstPass { typedef typename std::conditional<TRI == k
 
 // First pass without the hierarchy walk: spheres and the linear tables.
 template <int TRI, bool HAS_SPH>
-RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename FirstPass<TRI>::type &first) {
+RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename FirstPass<TRI>::type &first,
+                      SpherePre *pre = nullptr, float rel_accept = 0.0f, float abs_accept = 0.0f) {
     first.init(S);
     if (HAS_SPH) {
-        search_spheres(S, r, first);
+        if (pre != nullptr && S.n_sph_rows <= kFewSpheres) search_few_spheres(S, r, first, *pre, rel_accept, abs_accept);
+        else search_spheres(S, r, first);
         if (S.n_big_sph > 0) {
             const Ray64 x = ray64(r, rr);
             search_big_spheres(S, r, x.o, x.d, first);
@@ -762,7 +791,7 @@ RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename Fi
 // the hit (e64->hit says whether it did).
 template <int TRI, bool HAS_SPH, bool STRICT>
 RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
-                      BvhCounters bc, ExactHit *e64) {
+                      BvhCounters bc, ExactHit *e64, const SpherePre *pre = nullptr) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
     h.refined = false; h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
     const int route = ray_route<TRI>(r);
@@ -784,7 +813,9 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
                 const ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)gprim, x.o, x.d, gprim == r.origin, false);
                 status = eb.hit ? 0 : 2; t = (float)eb.t; thi = t * (1.0f + 2.0f * kU); root = eb.prim;
             } else {
-                SphVerdict v = judge_sphere(S, gprim, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
+                SphVerdict v;
+                if (pre != nullptr && pre->id == gprim) v = pre->v;   // worked out in the first pass already
+                else v = judge_sphere(S, gprim, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
                 status = v.status; t = v.t; thi = v.thi; root = v.root;
             }
         } else {
@@ -881,11 +912,13 @@ RT_DEV Hit closest_hit(SceneRef S, const Ray &r, ExactHit *e64, const RayResidue
     typename FirstPass<TRI>::type first;
     first.init(S);
     BvhCounters bc = bvh_counters();
+    SpherePre pre; pre.id = -1; pre.tl = kInf; pre.v.status = 2; pre.v.root = 0; pre.v.t = 0; pre.v.thi = 0;
     if (ray_route<TRI>(r) == kRouteFilter) {
-        hit_begin<TRI, HAS_SPH>(S, r, rr, first);
+        hit_begin<TRI, HAS_SPH>(S, r, rr, first, HAS_SPH ? &pre : nullptr, STRICT ? kRelAcceptStrict : kRelAcceptRender,
+                                STRICT ? 0.0f : kAbsAcceptRender * (r.o2 + S.scene_radius));
         if (TRI == kTriBvh) { int node = 0; search_bvh(S, r, first, bc, node, 0x7FFFFFFF); }
     }
-    return hit_finish<TRI, HAS_SPH, STRICT>(S, r, rr, first, bc, e64);
+    return hit_finish<TRI, HAS_SPH, STRICT>(S, r, rr, first, bc, e64, HAS_SPH ? &pre : nullptr);
 }
 
 }  // namespace rt
