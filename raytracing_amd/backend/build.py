@@ -12,10 +12,10 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "_rt_hip.so")
 SOURCES = ["rt_api.hip"]
-HEADERS = ["rt_scene.h", "rt_exact.h", "rt_filter.h", "rt_render.h", os.path.join("..", "..", "include", "raytracing_amd.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "raytracing_amd.h")]
 # -ffp-contract=off: the double-precision exact code must round like upstream's Python floats (no
 # fused multiply-add); the float32 kernels spell out every fma explicitly.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wno-pass-failed"]
 
 
 def needs_build() -> bool:

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/raytracing_amd.h"
@@ -511,13 +512,23 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         // Device form: eight threadings of the one hierarchy, one per octant of ray directions (children
         // nearer along the ray first), each laid out top levels first - the kernels stage those in LDS -
         // and depth-first below.
-        std::vector<rt_bvh_node> all, one, dev;
-        all.reserve(8 * bvh_nodes.size() + 1);
-        for (int oct = 0; oct < 8; ++oct) {
+        std::vector<rt_bvh_node> all(8 * bvh_nodes.size());
+        int32_t tops[8] = {0};
+        auto thread_octant = [&](int oct) {   // the eight threadings are independent of each other
+            std::vector<rt_bvh_node> one, dev;
             bvh::rethread(bvh_nodes, oct, one);
-            n_top_nodes = bvh::reorder_top_first(one, kTopNodes, dev);   // level sizes, hence the count, are the same for every octant
-            all.insert(all.end(), dev.begin(), dev.end());
+            tops[oct] = bvh::reorder_top_first(one, kTopNodes, dev);
+            std::copy(dev.begin(), dev.end(), all.begin() + (size_t)oct * bvh_nodes.size());
+        };
+        if (bvh_nodes.size() >= 65536) {
+            std::vector<std::thread> pool;
+            for (int oct = 1; oct < 8; ++oct) pool.emplace_back(thread_octant, oct);
+            thread_octant(0);
+            for (auto &t : pool) t.join();
+        } else {
+            for (int oct = 0; oct < 8; ++oct) thread_octant(oct);
         }
+        n_top_nodes = tops[0];   // level sizes, hence the count, are the same for every octant
         HIP_TRY(c, c->bvh.upload(all));
     }
 

@@ -13,9 +13,12 @@
 // terminates.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/raytracing_amd.h"
@@ -66,93 +69,204 @@ struct Builder {
         }
         nodes.clear();
         nodes.reserve((size_t)(2 * n / std::max(1, leaf_target)) + 16);
-        if (!order.empty()) build(0, (int32_t)order.size(), 0);
+        int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        if (const char *e = std::getenv("RAYTRACING_AMD_BUILD_THREADS")) threads = std::min(std::max(1, std::atoi(e)), kMaxThreads);
+        if (order.size() < 65536) threads = 1;
+        if (order.empty()) {}
+        else if (threads > 1) build_parallel(threads);
+        else build(nodes, 0, (int32_t)order.size(), 0);
         const int32_t total = (int32_t)nodes.size();
         for (auto &nd : nodes) if (nd.skip >= total) nd.skip = -1;
     }
 
-    void make_leaf(int32_t idx, int32_t begin, int32_t end) { nodes[idx].tri_begin_count = (begin << 4) | (end - begin); }
+    // Decides what the node over order[begin, end) is: its box, and either "leaf" or the split point
+    // `mid` (order is partitioned in place).
+    static constexpr int kMaxThreads = 16;
+    static constexpr int32_t kWideRange = 1 << 17;
+    int par_threads = 1;   // threads the passes over a range of kWideRange or more may use (set by build_parallel for the top of the tree)
 
-    void build(int32_t begin, int32_t end, int depth) {
-        const int32_t idx = (int32_t)nodes.size();
-        nodes.push_back(rt_bvh_node{});
-        Box bb; bb.reset();
+    // fn(thread, b, e) over [begin, end) in `par_threads` contiguous parts when the range is large
+    template <class F> void for_parts(int32_t begin, int32_t end, int &parts, F &&fn) {
+        parts = (par_threads > 1 && end - begin >= kWideRange) ? par_threads : 1;
+        if (parts == 1) { fn(0, begin, end); return; }
+        std::vector<std::thread> pool;
+        const int64_t len = end - begin;
+        for (int t = 1; t < parts; ++t)
+            pool.emplace_back([&, t]() { fn(t, begin + (int32_t)(len * t / parts), begin + (int32_t)(len * (t + 1) / parts)); });
+        fn(0, begin, begin + (int32_t)(len / parts));
+        for (auto &th : pool) th.join();
+    }
+
+    struct Bins { Box box[3][kBins]; int32_t n[3][kBins]; };
+
+    // Decides what the node over order[begin, end) is: its box, and either "leaf" or the split point
+    // `mid` (order is partitioned in place).
+    void split(int32_t begin, int32_t end, int depth, Box &bb, bool &leaf, int32_t &mid) {
+        bb.reset();
         Box cb; cb.reset();
-        for (int32_t i = begin; i < end; ++i) { bb.grow(tri_box[order[i]]); cb.grow(&centroid[3 * (size_t)order[i]]); }
-        for (int k = 0; k < 3; ++k) { nodes[idx].lo[k] = bb.lo[k]; nodes[idx].hi[k] = bb.hi[k]; }
-        nodes[idx].tri_begin_count = -1;
+        {
+            int parts;
+            Box pbb[kMaxThreads], pcb[kMaxThreads];
+            for_parts(begin, end, parts, [&](int t, int32_t b, int32_t e) {
+                Box x, y; x.reset(); y.reset();
+                for (int32_t i = b; i < e; ++i) { x.grow(tri_box[order[i]]); y.grow(&centroid[3 * (size_t)order[i]]); }
+                pbb[t] = x; pcb[t] = y;
+            });
+            for (int t = 0; t < parts; ++t) { bb.grow(pbb[t]); cb.grow(pcb[t]); }
+        }
         const int32_t count = end - begin;
-        bool leaf = count <= leaf_target;
-        int32_t mid = begin;
-        if (!leaf) {
-            // binned SAH over the three axes of the centroid box
-            double best_cost = INFINITY; int best_axis = -1, best_bin = -1;
-            for (int axis = 0; axis < 3; ++axis) {
-                const float c0 = cb.lo[axis], c1 = cb.hi[axis];
-                if (!(c1 > c0)) continue;
-                const float scale = (float)kBins / (c1 - c0);
-                Box bin_box[kBins]; int32_t bin_n[kBins];
-                for (int b = 0; b < kBins; ++b) { bin_box[b].reset(); bin_n[b] = 0; }
-                for (int32_t i = begin; i < end; ++i) {
-                    const int32_t t = order[i];
-                    int b = (int)((centroid[3 * (size_t)t + axis] - c0) * scale);
-                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                    bin_box[b].grow(tri_box[t]); bin_n[b]++;
-                }
-                double right_area[kBins]; int32_t right_n[kBins];
-                Box acc; acc.reset(); int32_t cnt = 0;
-                for (int b = kBins - 1; b > 0; --b) { acc.grow(bin_box[b]); cnt += bin_n[b]; right_area[b] = acc.half_area(); right_n[b] = cnt; }
-                acc.reset(); cnt = 0;
-                for (int b = 0; b < kBins - 1; ++b) {
-                    acc.grow(bin_box[b]); cnt += bin_n[b];
-                    if (cnt == 0 || right_n[b + 1] == 0) continue;
-                    const double cost = acc.half_area() * cnt + right_area[b + 1] * right_n[b + 1];
-                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+        leaf = count <= leaf_target;
+        mid = begin;
+        if (leaf) return;
+        // binned SAH over the three axes of the centroid box: one pass over the triangles fills the
+        // bins of all three axes (min / max and counts: the result does not depend on how the range
+        // is cut into parts)
+        float c0[3], scale[3]; bool usable[3];
+        for (int axis = 0; axis < 3; ++axis) {
+            c0[axis] = cb.lo[axis];
+            usable[axis] = cb.hi[axis] > cb.lo[axis];
+            scale[axis] = usable[axis] ? (float)kBins / (cb.hi[axis] - cb.lo[axis]) : 0.0f;
+        }
+        Bins one;                     // the usual case: this thread alone, no heap traffic per node
+        std::vector<Bins> many;
+        const bool wide = par_threads > 1 && end - begin >= kWideRange;
+        if (wide) many.resize(par_threads);
+        Bins *pbins = wide ? many.data() : &one;
+        int parts;
+        for_parts(begin, end, parts, [&](int t, int32_t b, int32_t e) {
+            Bins &B = pbins[t];
+            for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) { B.box[a][k].reset(); B.n[a][k] = 0; }
+            for (int32_t i = b; i < e; ++i) {
+                const int32_t tri = order[i];
+                const Box &tb = tri_box[tri];
+                for (int a = 0; a < 3; ++a) {
+                    if (!usable[a]) continue;
+                    int k = (int)((centroid[3 * (size_t)tri + a] - c0[a]) * scale[a]);
+                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    B.box[a][k].grow(tb); B.n[a][k]++;
                 }
             }
-            // a leaf of up to kMaxLeaf triangles is kept when no split is cheaper than testing them all
-            // (box test = 1, triangle test = 2 in units of the parent's area)
-            if (best_axis >= 0 && count <= kMaxLeaf) {
-                const double leaf_cost = 2.0 * count * bb.half_area();
-                if (1.0 * bb.half_area() + 2.0 * best_cost >= leaf_cost && count <= 2 * leaf_target) leaf = true;
-            }
-            if (!leaf) {
-                if (best_axis >= 0 && depth <= 48) {   // deeper than that: halve the list instead (bounded depth)
-                    const float c0 = cb.lo[best_axis], scale = (float)kBins / (cb.hi[best_axis] - c0);
-                    auto it = std::partition(order.begin() + begin, order.begin() + end, [&](int32_t t) {
-                        int b = (int)((centroid[3 * (size_t)t + best_axis] - c0) * scale);
-                        b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                        return b <= best_bin;
-                    });
-                    mid = (int32_t)(it - order.begin());
-                }
-                if (mid <= begin || mid >= end) {
-                    // all centroids coincide (or binning failed): split the list in half, which keeps the
-                    // depth logarithmic; if it is short enough it becomes a leaf instead
-                    if (count <= kMaxLeaf) leaf = true;
-                    else {
-                        int axis = 0;
-                        for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
-                        mid = begin + count / 2;
-                        std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end, [&](int32_t a, int32_t b) {
-                            return centroid[3 * (size_t)a + axis] < centroid[3 * (size_t)b + axis];
-                        });
-                    }
-                }
+        });
+        for (int t = 1; t < parts; ++t)
+            for (int a = 0; a < 3; ++a) for (int k = 0; k < kBins; ++k) { pbins[0].box[a][k].grow(pbins[t].box[a][k]); pbins[0].n[a][k] += pbins[t].n[a][k]; }
+        double best_cost = INFINITY; int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            if (!usable[axis]) continue;
+            const Box *bin_box = pbins[0].box[axis]; const int32_t *bin_n = pbins[0].n[axis];
+            double right_area[kBins]; int32_t right_n[kBins];
+            Box acc; acc.reset(); int32_t cnt = 0;
+            for (int b = kBins - 1; b > 0; --b) { acc.grow(bin_box[b]); cnt += bin_n[b]; right_area[b] = acc.half_area(); right_n[b] = cnt; }
+            acc.reset(); cnt = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                acc.grow(bin_box[b]); cnt += bin_n[b];
+                if (cnt == 0 || right_n[b + 1] == 0) continue;
+                const double cost = acc.half_area() * cnt + right_area[b + 1] * right_n[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
             }
         }
+        // a leaf of up to kMaxLeaf triangles is kept when no split is cheaper than testing them all
+        // (box test = 1, triangle test = 2 in units of the parent's area)
+        if (best_axis >= 0 && count <= kMaxLeaf) {
+            const double leaf_cost = 2.0 * count * bb.half_area();
+            if (1.0 * bb.half_area() + 2.0 * best_cost >= leaf_cost && count <= 2 * leaf_target) { leaf = true; return; }
+        }
+        if (best_axis >= 0 && depth <= 48) {   // deeper than that: halve the list instead (bounded depth)
+            const float c0 = cb.lo[best_axis], scale = (float)kBins / (cb.hi[best_axis] - c0);
+            auto it = std::partition(order.begin() + begin, order.begin() + end, [&](int32_t t) {
+                int b = (int)((centroid[3 * (size_t)t + best_axis] - c0) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= best_bin;
+            });
+            mid = (int32_t)(it - order.begin());
+        }
+        if (mid <= begin || mid >= end) {
+            // all centroids coincide (or binning failed): split the list in half, which keeps the
+            // depth logarithmic; if it is short enough it becomes a leaf instead
+            if (count <= kMaxLeaf) { leaf = true; return; }
+            int axis = 0;
+            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+            mid = begin + count / 2;
+            std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end, [&](int32_t a, int32_t b) {
+                return centroid[3 * (size_t)a + axis] < centroid[3 * (size_t)b + axis];
+            });
+        }
+    }
+
+    static void set_box(rt_bvh_node &nd, const Box &bb) { for (int k = 0; k < 3; ++k) { nd.lo[k] = bb.lo[k]; nd.hi[k] = bb.hi[k]; } }
+
+    // Subtree over order[begin, end) appended to `out` in threaded depth-first order; links are
+    // indices into `out` (a skip equal to out.size() at return means "whatever follows the subtree").
+    void build(std::vector<rt_bvh_node> &out, int32_t begin, int32_t end, int depth) {
+        const int32_t idx = (int32_t)out.size();
+        out.push_back(rt_bvh_node{});
+        Box bb; bool leaf; int32_t mid;
+        split(begin, end, depth, bb, leaf, mid);
+        set_box(out[idx], bb);
         if (leaf) {
-            if (count > kMaxLeaf) {   // cannot happen (leaves are only made at or below kMaxLeaf), kept as a guard
-                mid = begin + count / 2; leaf = false;
-            } else {
-                make_leaf(idx, begin, end);
-                nodes[idx].skip = (int32_t)nodes.size();
-                return;
-            }
+            out[idx].tri_begin_count = (begin << 4) | (end - begin);
+            out[idx].skip = (int32_t)out.size();
+            return;
         }
-        build(begin, mid, depth + 1);
-        build(mid, end, depth + 1);
-        nodes[idx].skip = (int32_t)nodes.size();
+        out[idx].tri_begin_count = -1;
+        build(out, begin, mid, depth + 1);
+        build(out, mid, end, depth + 1);
+        out[idx].skip = (int32_t)out.size();
+    }
+
+    // Large inputs: the top of the tree is split on this thread down to ranges of at most `grain`
+    // triangles, those subtrees are built on worker threads into vectors of their own, and the
+    // pieces are laid out in the same depth-first order a single-threaded build produces (the
+    // result is identical node for node).
+    struct Piece {
+        bool is_task; int32_t begin, end, depth;
+        rt_bvh_node node;            // top node (is_task == false)
+        int32_t end_piece;           // top node: index of the piece after its subtree
+        std::vector<rt_bvh_node> sub;
+    };
+    void top(std::vector<Piece> &pieces, int32_t begin, int32_t end, int depth, int32_t grain) {
+        Piece p{}; p.begin = begin; p.end = end; p.depth = depth;
+        if (end - begin <= grain) { p.is_task = true; pieces.push_back(std::move(p)); return; }
+        const size_t i = pieces.size();
+        pieces.push_back(std::move(p));
+        Box bb; bool leaf; int32_t mid;
+        split(begin, end, depth, bb, leaf, mid);
+        set_box(pieces[i].node, bb);
+        if (leaf) { pieces[i].node.tri_begin_count = (begin << 4) | (end - begin); pieces[i].end_piece = (int32_t)pieces.size(); return; }
+        pieces[i].node.tri_begin_count = -1;
+        top(pieces, begin, mid, depth + 1, grain);
+        top(pieces, mid, end, depth + 1, grain);
+        pieces[i].end_piece = (int32_t)pieces.size();
+    }
+    void build_parallel(int threads) {
+        const int32_t n = (int32_t)order.size();
+        std::vector<Piece> pieces;
+        par_threads = threads;
+        top(pieces, 0, n, 0, std::max<int32_t>(4096, n / (8 * threads)));
+        par_threads = 1;   // the workers below each run their subtree's passes on their own
+        std::vector<Piece *> tasks;
+        for (auto &p : pieces) if (p.is_task) tasks.push_back(&p);
+        std::sort(tasks.begin(), tasks.end(), [](const Piece *a, const Piece *b) { return a->end - a->begin > b->end - b->begin; });
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
+                Piece &p = *tasks[k];
+                p.sub.reserve((size_t)(2 * (p.end - p.begin) / std::max(1, leaf_target)) + 16);
+                build(p.sub, p.begin, p.end, p.depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        // lay the pieces out: offsets first, then nodes with their links moved
+        std::vector<int32_t> offset(pieces.size() + 1, 0);
+        for (size_t i = 0; i < pieces.size(); ++i) offset[i + 1] = offset[i] + (pieces[i].is_task ? (int32_t)pieces[i].sub.size() : 1);
+        nodes.resize((size_t)offset[pieces.size()]);
+        for (size_t i = 0; i < pieces.size(); ++i) {
+            const Piece &p = pieces[i];
+            if (!p.is_task) { rt_bvh_node nd = p.node; nd.skip = offset[p.end_piece]; nodes[offset[i]] = nd; continue; }
+            for (size_t k = 0; k < p.sub.size(); ++k) { rt_bvh_node nd = p.sub[k]; nd.skip += offset[i]; nodes[offset[i] + k] = nd; }
+        }
     }
 };
 

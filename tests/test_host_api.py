@@ -275,3 +275,20 @@ def test_app_helpers(tmp_path):
     app.save_image(img, str(p))
     back = np.asarray(Image.open(p))
     assert back.shape == (4, 7, 3) and tuple(back[0, 6]) == (255, 127, 255) and back.sum() == 255 + 127 + 255
+
+
+def test_threaded_hierarchy_build_equals_single_threaded(monkeypatch):
+    """Above 65,536 triangles rt_build_bvh splits the top of the tree on the calling thread (its
+    passes over large ranges shared among threads) and builds the subtrees below on workers; the
+    result is the single-threaded hierarchy node for node."""
+    from raytracing_amd.backend.bvh import build_flat_bvh, check_flat_bvh
+
+    base = h.packed_scene("room_horse")
+    tv = base.with_subdivided_mesh(base.n_meshes - 1, 5).tri_verts      # 295 k triangles
+    out = {}
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("RAYTRACING_AMD_BUILD_THREADS", threads)
+        out[threads] = build_flat_bvh(tv)
+    for threads in ("3", "8"):
+        assert np.array_equal(out["1"][0], out[threads][0]) and np.array_equal(out["1"][1], out[threads][1])
+    check_flat_bvh(out["8"][0], out["8"][1], tv)
