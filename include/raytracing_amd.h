@@ -130,7 +130,7 @@ const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: last error of 
 
 /* Host-side hierarchy builder (binned surface-area heuristic; CPU only, needs no context or GPU).
  * No upstream counterpart (upstream has no acceleration structure).  tri_verts = [n_tris][9] as in
- * rt_scene_desc; leaf_size = triangles per leaf to aim for (<= 0: 4).  Writes the leaf-order
+ * rt_scene_desc; leaf_size = triangles per leaf to aim for (<= 0: 3).  Writes the leaf-order
  * triangle ids to tri_index_out[n_tris], the node count to *n_nodes_out and, when nodes_out is
  * non-NULL and nodes_capacity suffices (2 * n_tris always does), the nodes.  Call with
  * nodes_out = NULL to learn the count first. */

@@ -17,7 +17,7 @@ NODE_DTYPE = np.dtype([("lo", np.float32, (3,)), ("skip", np.int32), ("hi", np.f
 assert NODE_DTYPE.itemsize == 32
 
 
-def build_flat_bvh(tri_verts: np.ndarray, leaf_size: int = 4) -> tuple[np.ndarray, np.ndarray]:
+def build_flat_bvh(tri_verts: np.ndarray, leaf_size: int = 3) -> tuple[np.ndarray, np.ndarray]:
     """(nodes, tri_index) for ``tri_verts`` of shape (n, 9) float64.
 
     ``nodes`` is a structured array in threaded depth-first order: the first child of an inner node

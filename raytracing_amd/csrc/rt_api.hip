@@ -191,7 +191,7 @@ int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_
                  int32_t *tri_index_out, int32_t *n_nodes_out) {
     if (n_tris <= 0 || n_tris >= (1 << 27) || !tri_verts || !tri_index_out || !n_nodes_out || nodes_capacity < 0) return RT_ERR_INVALID_ARG;
     bvh::Builder b;
-    b.run(n_tris, tri_verts, leaf_size > 0 ? leaf_size : 4);
+    b.run(n_tris, tri_verts, leaf_size > 0 ? leaf_size : 3);
     *n_nodes_out = (int32_t)b.nodes.size();
     std::memcpy(tri_index_out, b.order.data(), sizeof(int32_t) * (size_t)n_tris);
     if ((int64_t)b.nodes.size() > nodes_capacity || !nodes_out) return nodes_out ? RT_ERR_INVALID_ARG : RT_OK;
@@ -270,8 +270,8 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             for (int t = 0; t < d->n_tris; ++t) if (!linear_tri[t]) rest.push_back(t);
             if (rest.empty()) { rest.push_back(large.back()); linear_tri[large.back()] = 0; }   // keep the hierarchy non-empty
             bvh::Builder b;
-            const char *leaf_env = std::getenv("RAYTRACING_AMD_BVH_LEAF");   // tuning switch; default 4
-            b.run(d->n_tris, d->tri_verts, leaf_env ? std::atoi(leaf_env) : 4, &rest);
+            const char *leaf_env = std::getenv("RAYTRACING_AMD_BVH_LEAF");   // tuning switch; default 3 (measured 1 ... 8 on 310 ... 1.18 M triangles)
+            b.run(d->n_tris, d->tri_verts, leaf_env ? std::atoi(leaf_env) : 3, &rest);
             bvh_nodes.swap(b.nodes); bvh_order.swap(b.order);
         }
     }
