@@ -485,15 +485,17 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
     const TriRow *rows = S.leaf_rows;
     if (S.n_bvh_nodes <= 0) node = -1;
     int visited = 0;
-    // Each trip of the outer loop is a sub-slice: every lane walks boxes until it has found a leaf (it
-    // then goes on - the leaf waits), stands before a second one, or has used the sub-slice up; then
-    // all lanes that hold a leaf test its triangles TOGETHER.  Testing a leaf the moment a lane finds
-    // it would run the triangle code for that one lane while the others wait ("while-while" loops
-    // still did that three or four times per slice).
-    constexpr int kSubSlice = 4;   // measured on 310 ... 1.18 M triangles: 2 / 4 / 8 -> 4.58 / 4.84 / 4.72 G rays/s at 1.18 M
+    // Each trip of the outer loop is a sub-slice: every lane walks boxes until it has found two leaves
+    // (after the first it goes on - the leaf waits), stands before a third, or has used the sub-slice
+    // up; then all lanes that hold leaves test their triangles TOGETHER.  Testing a leaf the moment a
+    // lane finds it would run the triangle code for that one lane while the others wait ("while-while"
+    // loops still did that three or four times per slice).
+    // Measured at 1.18 M triangles, G rays/s: one pending leaf, sub-slices of 2 / 4 / 8 boxes:
+    // 4.58 / 4.84 / 4.72; two pending leaves, sub-slices of 4 / 6 / 8: 5.32 / 5.37 / 5.43; three: 5.60 against 5.55.
+    constexpr int kSubSlice = 8;
     while (visited < budget && node >= 0) {
         const int stop = visited + kSubSlice < budget ? visited + kSubSlice : budget;
-        int32_t leaf = -1;
+        int32_t leaf = -1, leaf2 = -1;
         while (node >= 0 && visited < stop) {
             f4 a, b;
             if (node < bc.n_top) { a = top[2 * node]; b = top[2 * node + 1]; }                // top levels: LDS
@@ -507,8 +509,9 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
             const float tf = min_(min_(max_(x0, x1), max_(y0, y1)), min_(max_(z0, z1), sink.prune_bound()));
             const bool hit = tn <= tf;
             if (hit && info >= 0) {
-                if (leaf >= 0) break;        // a second leaf: it is met again (and counted) next time round
-                leaf = info; node = skip;
+                if (leaf2 >= 0) break;       // a third leaf: it is met again (and counted) next time round
+                if (leaf >= 0) leaf2 = info; else leaf = info;
+                node = skip;
             } else {
                 node = hit ? (info == -1 ? node + 1 : -info - 2) : skip;   // inner node: first child, given or next
             }
@@ -516,10 +519,11 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
             bc.nodes++;
         }
         if (leaf >= 0) {
-            const int first = leaf >> 4, cnt = leaf & 15;
+            const int first = leaf >> 4, cnt0 = leaf & 15;
+            const int first2 = leaf2 >= 0 ? leaf2 >> 4 : 0, cnt = cnt0 + (leaf2 >= 0 ? leaf2 & 15 : 0);
             bc.tris += (uint32_t)cnt;
             for (int k = 0; k < cnt; ++k) {
-                const TriRow cur = load_tri_row_lane(rows, first + k);
+                const TriRow cur = load_tri_row_lane(rows, k < cnt0 ? first + k : first2 + (k - cnt0));
                 float sure_thi;
                 const float tl = tri_tlo<true>(cur, r, &sure_thi);
                 sink.certain_hit(sure_thi);
