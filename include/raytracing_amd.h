@@ -81,8 +81,9 @@ typedef struct rt_scene_desc {
     /* Optional flat bounding-volume hierarchy over ALL triangles (no upstream counterpart: it
      * replaces the linear loops of Mesh.intersect, src/mesh/mesh.py:94-107, and returns the same
      * hits).  n_bvh_nodes > 0: the caller's hierarchy (checked: links, coverage, containment);
-     * n_bvh_nodes == 0: linear table walk up to 4096 primitives, a hierarchy built by the library
-     * beyond that; n_bvh_nodes < 0: the library builds one whatever the size.  Layout: rt_bvh_node. */
+     * n_bvh_nodes == 0: linear table walk up to 48 triangles (and 4096 primitives), a hierarchy built
+     * by the library beyond that; n_bvh_nodes < 0: the library builds one whatever the size.
+     * Layout: rt_bvh_node. */
     int32_t n_bvh_nodes;
     const void *bvh_nodes;         /* [n_bvh_nodes] rt_bvh_node */
     const int32_t *bvh_tri_index;  /* [n_tris] triangle ids in leaf order */

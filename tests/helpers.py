@@ -95,6 +95,21 @@ class origin_rule:
         oracle().orc_set_origin_rule(0)
 
 
+class linear_tables:
+    """Context manager: rt_set_scene keeps up to 4096 triangles in the linear tables (the default
+    leaves them at a few dozen), for tests that compare the two search structures."""
+
+    def __enter__(self):
+        self.old = os.environ.get("RAYTRACING_AMD_LINEAR_MAX_TRIS")
+        os.environ["RAYTRACING_AMD_LINEAR_MAX_TRIS"] = "4096"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("RAYTRACING_AMD_LINEAR_MAX_TRIS", None)
+        else:
+            os.environ["RAYTRACING_AMD_LINEAR_MAX_TRIS"] = self.old
+
+
 def oracle_intersect(scene: PackedScene, org: np.ndarray, dirs: np.ndarray, origin_prim=None):
     lib = oracle()
     n = org.shape[0]

@@ -64,7 +64,11 @@ def test_small_mesh_all_search_modes(backend, mode):
 
         nodes, order = build_flat_bvh(sc.tri_verts)
         sc = dataclasses.replace(sc, bvh_nodes=nodes, bvh_tri_index=order)
-    backend.set_scene(sc)
+    if mode == "linear":
+        with h.linear_tables():          # (left to itself the library takes the hierarchy above 48 triangles)
+            backend.set_scene(sc)
+    else:
+        backend.set_scene(sc)
     z, o32, d32 = _path_rays()
     want = h.oracle_intersect(sc, o32, d32)
     backend.reset_stats()
@@ -126,7 +130,11 @@ def test_render_hierarchy_equals_linear_walk(backend):
     imgs = []
     for lib_bvh in (False, True):
         sc = dataclasses.replace(h.packed_scene("room_horse"), library_bvh=lib_bvh)
-        backend.set_scene(sc)
+        if lib_bvh:
+            backend.set_scene(sc)
+        else:
+            with h.linear_tables():
+                backend.set_scene(sc)
         backend.resize(W, H)
         backend.reset_stats()
         backend.render(W, H, 0, spp, b, h.SEED_RENDER)

@@ -864,7 +864,8 @@ def test_random_soup_of_every_row_kind(backend, seed):
                              spheres=np.ascontiguousarray(sph), sphere_obj=np.arange(n_sph, dtype=np.int32) + n_mesh,
                              mesh_aabb=np.ascontiguousarray(aabb), mesh_obj=np.arange(n_mesh, dtype=np.int32),
                              mesh_tri_begin=begin, tri_verts=np.ascontiguousarray(tv), object_names=["x"] * (n_mesh + n_sph))
-    backend.set_scene(sc)
+    with h.linear_tables():
+        backend.set_scene(sc)
     n = 40000
     o = rng.uniform(-1.3, 1.3, (n, 3)).astype(np.float32).astype(np.float64)
     d = rng.normal(size=(n, 3))
