@@ -210,6 +210,19 @@ typedef struct rt_postprocess_params {
 int rt_postprocess(rt_ctx *ctx, const float *src_dev, int32_t width, int32_t height, float scale, int32_t flip_y,
                    const rt_postprocess_params *params, float *dst_dev, void *stream);
 
+/* rt_postprocess for callers that cannot allocate.  No counterpart upstream: it exists for code under
+ * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same
+ * kernels and bit-identical output; the per-block reduction slots live in a fixed device array inside
+ * the library (32,784 bytes per GPU, held until the process ends) instead of a context buffer, so the
+ * call makes no hipMalloc / hipFree, no synchronisation and no allocating library call - three kernel
+ * launches on `stream`, nothing else.  Images of more than RT_NOALLOC_MAX_PIXELS pixels are refused
+ * with RT_ERR_INVALID_ARG (use rt_postprocess).  All calls on one GPU share the one array: calls that
+ * may overlap there (different streams, different contexts of the same GPU) race on it and must be
+ * ordered by the caller.  Nothing in the array needs to be zero between calls. */
+#define RT_NOALLOC_MAX_PIXELS (1 << 26)
+int rt_postprocess_noalloc(rt_ctx *ctx, const float *src_dev, int32_t width, int32_t height, float scale, int32_t flip_y,
+                           const rt_postprocess_params *params, float *dst_dev, void *stream);
+
 /* Renderer.stop_render (renderer.py:149-150): later rt_render calls return RT_ERR_STOPPED until
  * rt_clear_stop. */
 int rt_request_stop(rt_ctx *ctx);

@@ -24,7 +24,7 @@ RT_ERR_STOPPED = 5
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
            "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms",
-           "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_build_bvh", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
+           "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
 
 class RtRenderParams(C.Structure):
@@ -93,6 +93,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_raytrace_batch.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_uint64,
                                       C.c_uint32, C.c_uint32, fp]
     lib.rt_postprocess.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.POINTER(RtPostprocessParams), vp, vp]
+    lib.rt_postprocess_noalloc.argtypes = lib.rt_postprocess.argtypes
     lib.rt_build_bvh.argtypes = [C.c_int32, dp, C.c_int32, vp, C.c_int32, ip, ip]
     lp = C.POINTER(C.c_int64)
     lib.rt_obj_open.argtypes = [C.c_char_p, C.POINTER(vp), ip, lp, lp]
@@ -188,13 +189,15 @@ class HipBackend:
 
     def postprocess(self, width: int, height: int, dst_ptr: int, src_ptr: int = 0, scale: float = 1.0, flip_y: bool = False,
                     exposure=1.0, brightness=0.0, contrast=1.0, saturation=1.0, gamma=1.0, key=0.18, tone_saturation=1.0,
-                    stream: int = 0) -> None:
+                    stream: int = 0, no_alloc: bool = False) -> None:
         """Fused post-processing chain from a (W, H, 3) float32 device buffer (0 = the context's
-        accumulation buffer) into another; asynchronous on ``stream``."""
+        accumulation buffer) into another; asynchronous on ``stream``.  ``no_alloc`` takes the entry
+        point that works over the library's fixed scratch array and allocates nothing."""
         p = RtPostprocessParams(C.sizeof(RtPostprocessParams), exposure, brightness, contrast, saturation, gamma, key,
                                 tone_saturation)
-        self._check(self.lib.rt_postprocess(self.handle, C.c_void_p(src_ptr or None), width, height, scale, int(bool(flip_y)),
-                                            C.byref(p), C.c_void_p(dst_ptr), C.c_void_p(stream or None)))
+        entry = self.lib.rt_postprocess_noalloc if no_alloc else self.lib.rt_postprocess
+        self._check(entry(self.handle, C.c_void_p(src_ptr or None), width, height, scale, int(bool(flip_y)),
+                          C.byref(p), C.c_void_p(dst_ptr), C.c_void_p(stream or None)))
 
     def synchronize(self, stream: int = 0) -> None:
         self._check(self.lib.rt_synchronize(self.handle, C.c_void_p(stream or None)))

@@ -54,6 +54,34 @@ struct DevBuf {
 
 struct EventPair { hipEvent_t a, b; };
 
+// Fixed device-side scratch of rt_postprocess_noalloc: the per-block reduction slots of k_post_measure
+// plus the folded pair, laid out as PostArgs::partials.  Every GPU the library touches holds its own
+// copy of this array (32,784 bytes) at its own address until the process ends.  In host code the
+// array's NAME is only a handle for hipGetSymbolAddress; the address kernels and copies use is the
+// one looked up per device in scratch_for_device().
+constexpr int kPostScratchBlocks = 2048;
+static __device__ __align__(256) double scratch[2 * kPostScratchBlocks + 2];
+
+constexpr int kMaxScratchDevices = 64;
+std::mutex g_scratch_mu;
+double *g_scratch_ptr[kMaxScratchDevices] = {nullptr};
+
+// Device address of `scratch` on `device`, which must be the current device.  Looked up once per device.
+hipError_t scratch_for_device(int device, double **out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxScratchDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        double *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 }  // namespace
 
 struct rt_ctx {
@@ -70,6 +98,7 @@ struct rt_ctx {
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
     DevBuf post_partials;   // rt_postprocess: per-block reduction slots
+    double *post_scratch = nullptr;   // rt_postprocess_noalloc: this GPU's copy of the static scratch array
     DevBuf wf_rays[2], wf_paths, wf_hits, wf_radiance, wf_counters, wf_partials;   // wavefront form (hierarchy scenes)
     DevBuf ray_dir, ray_res; int ray_w = 0, ray_h = 0;   // camera-ray table of the current scene at ray_w x ray_h
     std::vector<EventPair> timed;        // recorded around render launches, not yet read
@@ -140,6 +169,13 @@ int rt_create(int device_id, rt_ctx **out) {
         hipMemset(c->stats.p, 0, sizeof(unsigned long long) * kStatCount) != hipSuccess) {
         delete c;
         return fail(nullptr, RT_ERR_HIP, "device %d: initial allocation failed", device_id);
+    }
+    {
+        const hipError_t e = scratch_for_device(device_id, &c->post_scratch);   // device_id is current here
+        if (e != hipSuccess) {
+            delete c;
+            return fail(nullptr, RT_ERR_HIP, "device %d: hipGetSymbolAddress(scratch) failed: %s", device_id, hipGetErrorString(e));
+        }
     }
     *out = c;
     return RT_OK;
@@ -1046,32 +1082,72 @@ extern "C" int rt_raytrace_batch(rt_ctx *c, int64_t n, const double *org, const 
 // ---------------------------------------------------------------------------------------------
 // post-processing (see rt_post.h)
 // ---------------------------------------------------------------------------------------------
-extern "C" int rt_postprocess(rt_ctx *c, const float *src_dev, int32_t width, int32_t height, float scale, int32_t flip_y,
-                              const rt_postprocess_params *p, float *dst_dev, void *stream_) {
-    if (!c || !p || !dst_dev) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: NULL argument");
+namespace {
+
+// Argument checks and the three launches shared by rt_postprocess and rt_postprocess_noalloc; the
+// two differ only in where the reduction slots live.
+int postprocess_check(rt_ctx *c, const char *who, const float *src_dev, int32_t width, int32_t height, int32_t flip_y,
+                      const rt_postprocess_params *p, float *dst_dev, const float **src_out) {
+    if (!c || !p || !dst_dev) return fail(c, RT_ERR_INVALID_ARG, "%s: NULL argument", who);
     if (p->struct_size != sizeof(rt_postprocess_params)) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess_params.struct_size mismatch");
-    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28)) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: bad size %d x %d", width, height);
-    if (!(p->tone_saturation > 0.0f) || !(p->key > 0.0f)) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: key and tone_saturation must be positive");
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28)) return fail(c, RT_ERR_INVALID_ARG, "%s: bad size %d x %d (at most 2^28 pixels)", who, width, height);
+    if (!(p->tone_saturation > 0.0f) || !(p->key > 0.0f)) return fail(c, RT_ERR_INVALID_ARG, "%s: key and tone_saturation must be positive", who);
     const float *src = src_dev;
     if (!src) {
-        if (c->acc_w != width || c->acc_h != height) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: context buffer is %dx%d, not %dx%d", c->acc_w, c->acc_h, width, height);
+        if (c->acc_w != width || c->acc_h != height) return fail(c, RT_ERR_INVALID_ARG, "%s: context buffer is %dx%d, not %dx%d", who, c->acc_w, c->acc_h, width, height);
         src = c->accum.as<float>();
     }
-    if (src == dst_dev && flip_y) return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess: in place only without the flip");
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t stream = (hipStream_t)stream_;
+    if (src == dst_dev && flip_y) return fail(c, RT_ERR_INVALID_ARG, "%s: in place only without the flip", who);
+    *src_out = src;
+    return RT_OK;
+}
+
+int postprocess_launch(rt_ctx *c, const float *src, int32_t width, int32_t height, float scale, int32_t flip_y,
+                       const rt_postprocess_params *p, float *dst_dev, double *partials, int n_blocks, hipStream_t stream) {
     const long long n = (long long)width * height;
-    const int n_blocks = (int)std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8);
-    const size_t need = (size_t)(2 * n_blocks + 2) * sizeof(double);
-    if (need > c->post_partials.bytes) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, c->post_partials.ensure(need)); }
     PostArgs A{};
     A.src = src; A.dst = dst_dev; A.width = width; A.height = height; A.flip_y = flip_y ? 1 : 0; A.scale = scale;
     A.exposure = p->exposure; A.brightness = p->brightness; A.contrast = p->contrast; A.saturation = p->saturation; A.gamma = p->gamma;
     A.key = p->key; A.tone_saturation = p->tone_saturation;
-    A.partials = c->post_partials.as<double>(); A.n_blocks = n_blocks;
+    A.partials = partials; A.n_blocks = n_blocks;
     hipLaunchKernelGGL(k_post_measure, dim3((unsigned)n_blocks), dim3(256), 0, stream, A);
     hipLaunchKernelGGL(k_post_fold, dim3(1), dim3(64), 0, stream, A);
     hipLaunchKernelGGL(k_post_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, A);
     HIP_TRY(c, hipGetLastError());
     return RT_OK;
+}
+
+int post_blocks(const rt_ctx *c, int32_t width, int32_t height) {
+    const long long n = (long long)width * height;
+    return (int)std::min<long long>({(n + 255) / 256, (long long)c->n_cu * 8, (long long)kPostScratchBlocks});
+}
+
+}  // namespace
+
+extern "C" int rt_postprocess(rt_ctx *c, const float *src_dev, int32_t width, int32_t height, float scale, int32_t flip_y,
+                              const rt_postprocess_params *p, float *dst_dev, void *stream_) {
+    const float *src = nullptr;
+    if (int st = postprocess_check(c, "rt_postprocess", src_dev, width, height, flip_y, p, dst_dev, &src)) return st;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int n_blocks = post_blocks(c, width, height);
+    const size_t need = (size_t)(2 * n_blocks + 2) * sizeof(double);
+    if (need > c->post_partials.bytes) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, c->post_partials.ensure(need)); }
+    return postprocess_launch(c, src, width, height, scale, flip_y, p, dst_dev, c->post_partials.as<double>(), n_blocks, (hipStream_t)stream_);
+}
+
+// rt_postprocess over the fixed scratch array: no hipMalloc / hipFree / synchronisation, only three
+// kernel launches on `stream`.  The reduction slots are written in full before they are read, so
+// nothing has to be cleared between calls; calls that overlap on one GPU (two streams, two contexts
+// or two processes' worth of threads in this process) share the array and race.
+extern "C" int rt_postprocess_noalloc(rt_ctx *c, const float *src_dev, int32_t width, int32_t height, float scale, int32_t flip_y,
+                                      const rt_postprocess_params *p, float *dst_dev, void *stream_) {
+    const float *src = nullptr;
+    if (int st = postprocess_check(c, "rt_postprocess_noalloc", src_dev, width, height, flip_y, p, dst_dev, &src)) return st;
+    if ((long long)width * height > RT_NOALLOC_MAX_PIXELS)
+        return fail(c, RT_ERR_INVALID_ARG, "rt_postprocess_noalloc: %d x %d is more than the %lld pixels this entry point takes; use rt_postprocess",
+                    width, height, (long long)RT_NOALLOC_MAX_PIXELS);
+    if (!c->post_scratch) return fail(c, RT_ERR_HIP, "rt_postprocess_noalloc: no scratch address for device %d", c->device);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int n_blocks = post_blocks(c, width, height);   // <= kPostScratchBlocks, which the array holds
+    return postprocess_launch(c, src, width, height, scale, flip_y, p, dst_dev, c->post_scratch, n_blocks, (hipStream_t)stream_);
 }
