@@ -61,7 +61,7 @@ def run(render_settings, post_processor=None, out_path: Optional[str] = None, wi
     shown = {"img": render_result.img_arr.copy()}
 
     def update_post_processing():   # main.py:183-187
-        while not renderer.stop_event.is_set() and not render_result.finished:
+        while not renderer.stop_event.is_set() and not render_result.finished and not render_result.failed:
             render_result.update_views()
             if render_result.rendered_passes > 0:
                 shown["img"] = post_processor.process(render_result.img_arr)
@@ -106,12 +106,20 @@ def run(render_settings, post_processor=None, out_path: Optional[str] = None, wi
                 time.sleep(1.0 / poll_hz)
             if render_result.finished:
                 break
+            # The render thread is the only one that can set `finished`: if it ended without doing so
+            # (a library error, kept in render_result.error, or a stop request) waiting on is pointless.
+            if render_result.failed or not renderer.is_rendering():
+                break
     except KeyboardInterrupt:
         renderer.stop_render()
         renderer.wait(10)
         return render_result, shown["img"]
     renderer.wait()
     pp_thread.join(5)
+    if render_result.failed:
+        if pg is not None:
+            pg.quit()
+        raise RuntimeError(f"render failed: {render_result.error}") from render_result.error
     render_result.update_views()
     final = post_processor.process(render_result.img_arr)   # main.py:210-217
     if out_path:
@@ -154,7 +162,11 @@ def main(argv=None) -> int:
             last["t"] = now
             print(text, file=sys.stderr, flush=True)
 
-    res, _ = run(settings, pp, out, window=a.window, device=a.device, seed=a.seed, on_tick=tick)
+    try:
+        res, _ = run(settings, pp, out, window=a.window, device=a.device, seed=a.seed, on_tick=tick)
+    except RuntimeError as e:
+        print(str(e), file=sys.stderr)
+        return 2
     print(f"{'finished' if res.finished else 'stopped'}: {res.rendered_passes} passes, "
           f"{res.stats.get('rays', 0)} rays, kernel {res.stats.get('kernel_ms', 0.0):.1f} ms -> {out}")
     return 0 if res.finished else 1

@@ -73,11 +73,15 @@ class Mesh(ObjectBase):
     def __init__(self, material: Material, origin: Vec3, vertices, triangles,
                  scale: Vec3 | None = None, rotation: Vec3 | None = None) -> None:
         super().__init__(material, origin)
+        # Change counter: every assignment to vertices / triangles / transformed_vertices bumps it, so
+        # that a scene can tell "this mesh changed since it was uploaded" without reading a vertex and
+        # without relying on array identities (CPython reuses the addresses of freed arrays).
+        self._version = 0
         self._vertices = np.zeros((0, 3))
         self._triangles = np.zeros((0, 3), dtype=np.int32)
         self.scale: Vec3 = scale if scale else Vec3(1)
         self.rotation: Vec3 = rotation if rotation else Vec3(0)
-        self.transformed_vertices: np.ndarray = np.zeros((0, 3))
+        self.transformed_vertices = np.zeros((0, 3))
         self.bounding_box: tuple[Vec3, Vec3] | None = None
         self.vertices = vertices
         self.triangles = triangles
@@ -93,6 +97,7 @@ class Mesh(ObjectBase):
         arr = np.asarray([tuple(v) for v in value] if len(value) and not isinstance(value, np.ndarray) else value,
                          dtype=np.float64)
         self._vertices = arr.reshape(-1, 3)
+        self._version += 1
 
     @property
     def triangles(self) -> np.ndarray:
@@ -101,6 +106,25 @@ class Mesh(ObjectBase):
     @triangles.setter
     def triangles(self, value) -> None:
         self._triangles = np.asarray(value, dtype=np.int32).reshape(-1, 3)
+        self._version += 1
+
+    @property
+    def transformed_vertices(self) -> np.ndarray:
+        return self._transformed_vertices
+
+    @transformed_vertices.setter
+    def transformed_vertices(self, value) -> None:
+        self._transformed_vertices = np.asarray(value, dtype=np.float64).reshape(-1, 3)
+        self._version += 1
+
+    @property
+    def version(self) -> int:
+        """Bumped by every change of the geometry (setters, transforms, ``touch``)."""
+        return self._version
+
+    def touch(self) -> None:
+        """Declare an in-place edit of one of the arrays (``mesh.transformed_vertices[i] = ...``)."""
+        self._version += 1
 
     # -- transforms (mesh.py:145-176) ----------------------------------------------------------
     def get_scaled_vertices(self, points) -> np.ndarray:
@@ -147,6 +171,7 @@ class Mesh(ObjectBase):
             return
         com = self._vertices.sum(axis=0) / self._vertices.shape[0]
         self._vertices = self._vertices - com
+        self._version += 1
         self.origin = Vec3(self.origin) + Vec3(com)
         self.update_transformed_vertices()
 

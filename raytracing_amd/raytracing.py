@@ -142,18 +142,30 @@ class Scene:
     # -- closest hit (GPU) ----------------------------------------------------------------------
     def fingerprint(self) -> tuple:
         """What the device copy of this scene depends on, cheap to compute (no vertex is read):
-        object identities and order, material values, sphere centres and radii, the identity of each
-        mesh's transformed-vertex and triangle arrays (the mesh setters - mesh.py:178-209 -
-        replace those arrays), camera and environment.  A changed fingerprint means the tables on
-        the GPU are stale."""
+        object identities and order, material values, sphere centres and radii, each mesh's change
+        counter (``Mesh.version``: every setter - mesh.py:178-209 - and every assignment to its
+        arrays bumps it), camera and environment.  A changed fingerprint means the tables on the GPU
+        are stale.  Array identities are NOT used: the setters free one array and allocate the next,
+        and CPython hands the same address out again.  Mesh-like objects without a change counter
+        (upstream's own ``Mesh``) are keyed on their transform values, vertex and face counts and
+        the bounding box their setters recompute."""
         def mat(m):
             return (tuple(m.color), float(m.emission_strength), float(m.smoothness), float(m.transmittance), float(m.ior))
+
+        def vec(v):
+            return None if v is None else tuple(float(x) for x in v)
+
         objs = []
         for o in self.objects:
             if hasattr(o, "radius"):
                 objs.append((id(o), mat(o.material), tuple(o.origin), float(o.radius)))
+            elif hasattr(o, "version"):
+                objs.append((id(o), mat(o.material), int(o.version)))
             else:
-                objs.append((id(o), mat(o.material), id(o.transformed_vertices), id(o.triangles)))
+                bb = getattr(o, "bounding_box", None)
+                objs.append((id(o), mat(o.material), vec(getattr(o, "origin", None)), vec(getattr(o, "rotation", None)),
+                             vec(getattr(o, "scale", None)), len(o.transformed_vertices), len(o.triangles),
+                             None if bb is None else (vec(bb[0]), vec(bb[1]))))
         c = self.camera
         cam = (tuple(c.pos), tuple(c.right), tuple(c.up), tuple(c.forward), float(c.d), float(c.dof_strength), float(c.dof_dist))
         sky = None if self.skybox is None else (id(self.skybox.rgb), float(self.skybox.scale))
@@ -226,7 +238,10 @@ class RenderResult:
         self.img_arr_clipped = np.zeros_like(self.arr)
         self.surface = None
         self.stats: dict = {}
+        self.error: Optional[BaseException] = None   # what ended a background render abnormally
+        self.failed = False                          # terminal like `finished`, but without an image
         self._backend = None
+        self._stale = False                          # render_area launched work `arr` does not show yet
         self._lock = threading.Lock()
 
     def add_to_px(self, x: int, y: int, v) -> None:
@@ -243,6 +258,12 @@ class RenderResult:
         return self.progress * 100
 
     def update_views(self) -> None:
+        if self._stale and self._backend is not None:   # tiles rendered through render_area since the last read-back
+            self._backend.synchronize()
+            arr = self._backend.read().astype(np.float64)
+            with self._lock:
+                self.arr = arr
+                self._stale = False
         self.update_img_arr()
         self.update_img_arr_clipped()
 
@@ -305,6 +326,7 @@ class Renderer:
         self._thread: Optional[Thread] = None
         self._raytrace_calls = 0
         self._scene_key = None
+        self._tile_passes: dict = {}   # render_area: passes already launched per tile
 
     # -- set-up ---------------------------------------------------------------------------------
     def init_render(self, render_settings: RenderSettings) -> None:
@@ -318,6 +340,7 @@ class Renderer:
         self.render_result = RenderResult(render_settings.WIDTH, render_settings.HEIGHT, render_settings.RENDER_PASSES)
         self.scene = render_settings.SCENE
         self.stop_event.clear()
+        self._tile_passes = {}
         # One context per renderer, kept across renders; the scene tables are uploaded again only
         # when the scene changed (objects moved by the mesh setters, materials, camera, environment).
         be = self._backend if self._backend is not None else HipBackend(self.device)
@@ -354,31 +377,66 @@ class Renderer:
 
     def render_area(self, area: Tuple[int, int, int, int]) -> None:
         """One pass (one more sample per pixel) over ``area``; upstream's per-tile entry point
-        (renderer.py:90-106).  The sample index is the number of passes already accumulated."""
+        (renderer.py:90-106).  Each tile keeps its own count of passes, which is the sample index of
+        its next call: a caller that drives the tiles itself (upstream's loop: all tiles, then
+        ``rendered_passes += 1``; or any other order) gets a fresh sample per call and tile, never
+        the same one twice.  The host copy ``render_result.arr`` is NOT refreshed here - a
+        whole-frame read-back per tile would dominate - but by ``Renderer.refresh()`` or
+        ``RenderResult.update_views()``."""
         if self.stop_event.is_set():
             return
         res = self.render_result
-        self._launch(area, res.rendered_passes, 1)
-        self._backend.synchronize()
+        area = tuple(int(v) for v in area)
+        with res._lock:
+            sample = self._tile_passes.get(area, res.rendered_passes)
+            self._tile_passes[area] = sample + 1
+        self._launch(area, sample, 1)
         x0, x1, y0, y1 = area
-        res.arr = self._backend.read().astype(np.float64)
-        res.rendered_pixels += (x1 - x0) * (y1 - y0)
+        with res._lock:
+            res.rendered_pixels += (x1 - x0) * (y1 - y0)
+            res._stale = True
+
+    def refresh(self) -> None:
+        """Bring ``render_result.arr`` up to date with the device buffer (waits for launched work)."""
+        res = self.render_result
+        self._backend.synchronize()
+        arr = self._backend.read().astype(np.float64)
+        with res._lock:
+            res.arr = arr
+            res._stale = False
 
     def render(self, vertical_splits: int = 1, horizontal_splits: int = 1) -> None:
         """All passes over the whole image.  The tile arguments are accepted for compatibility; the
-        device schedules (pixel, sample-chunk) jobs itself, so tiles buy nothing here."""
+        device schedules (pixel, sample-chunk) jobs itself, so tiles buy nothing here.
+
+        Runs on the background thread ``start_render`` starts, so it must not die silently: a stop
+        request that lands between the check and the launch comes back from the library as
+        RT_ERR_STOPPED and ends the loop cleanly; any other library error is kept in
+        ``render_result.error`` and ``render_result.failed`` is set, which pollers treat as terminal."""
+        from .backend.lib import RT_ERR_STOPPED, BackendError
+
         s, res = self.render_settings, self.render_result
         total = s.RENDER_PASSES
         step = self.samples_per_launch or total
         done = 0
-        while done < total and not self.stop_event.is_set():
-            n = min(step, total - done)
-            self._launch((0, s.WIDTH, 0, s.HEIGHT), done, n)
-            self._backend.synchronize()
-            done += n
-            self._publish(done, done * res.PX_NUM)
-        res.stats = self._backend.stats()
-        res.finished = done >= total
+        try:
+            while done < total and not self.stop_event.is_set():
+                n = min(step, total - done)
+                self._launch((0, s.WIDTH, 0, s.HEIGHT), done, n)
+                self._backend.synchronize()
+                done += n
+                self._publish(done, done * res.PX_NUM)
+            res.stats = self._backend.stats()
+        except BackendError as e:
+            if e.status != RT_ERR_STOPPED:
+                res.error = e
+                res.failed = True
+        except BaseException as e:   # anything else on this thread would otherwise vanish with it
+            res.error = e
+            res.failed = True
+            raise
+        finally:
+            res.finished = done >= total and not res.failed
 
     def start_executor(self, vertical_splits, horizontal_splits) -> None:
         self._thread = Thread(target=self.render, args=(vertical_splits, horizontal_splits), daemon=True)
@@ -397,6 +455,10 @@ class Renderer:
         if self._backend is not None:
             self._backend.request_stop()
 
+    def is_rendering(self) -> bool:
+        """True while the background thread of ``start_render`` is alive."""
+        return self._thread is not None and self._thread.is_alive()
+
     def wait(self, timeout: Optional[float] = None) -> None:
         if self._thread is not None:
             self._thread.join(timeout)
@@ -406,9 +468,18 @@ class Renderer:
         if self.render_settings is None:
             raise RuntimeError("Renderer.raytrace needs render_settings (MAX_BOUNCES) and a scene: call init_render first "
                                "or set .scene and .render_settings")
+        scene = self.scene if self.scene is not None else getattr(self.render_settings, "SCENE", None)
+        if self._backend is not None and scene is None:
+            return self._backend   # a context handed in ready-made: nothing to compare it with
         if self._backend is not None:
+            # the renderer's own context: re-upload if the scene was edited since init_render
+            from .backend.packer import pack_scene
+
+            key = (id(scene), scene.fingerprint())
+            if self._scene_key != key:
+                self._backend.set_scene(pack_scene(scene))
+                self._scene_key = key
             return self._backend
-        scene = self.scene if self.scene is not None else self.render_settings.SCENE
         return scene._device_scene(self.device)
 
     def raytrace_batch(self, origins, directions, inside=None, depth: int = 0, sample: Optional[int] = None) -> np.ndarray:

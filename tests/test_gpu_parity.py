@@ -473,6 +473,42 @@ def test_moved_objects_are_uploaded_again(backend):
     assert np.abs(a - b).max() > 0.05
     assert np.array_equal(b, r2.render_result.arr)
 
+    # Any number of setter calls between two looks is seen (the detector is a change counter, not an
+    # array identity: CPython reuses the addresses of the arrays the setters free).
+    for n in range(1, 9):
+        for k in range(n):
+            scene.objects[1].set_rotation(Vec3(0, 30.0 + 2.0 * n + 0.5 * k, 0))
+            scene.objects[1].set_origin(Vec3(0.1 * n, 0.05 * k, 4 + 0.1 * k))
+        got = scene.intersect(ray)
+        want = build((0.1 * n, 0.05 * (n - 1), 4 + 0.1 * (n - 1)), (0, 30.0 + 2.0 * n + 0.5 * (n - 1), 0)).intersect(ray)
+        assert len(got) == len(want) == 1
+        assert got[0].primitive == want[0].primitive and abs(got[0].depth - want[0].depth) <= 1e-12 * want[0].depth, n
+        # the renderer's own context notices too, without init_render (Renderer.raytrace between renders)
+        L0 = r.raytrace_batch([(0.5, 0.2, -3)], [(0, 0, 1)], sample=1)
+        L1 = r2.raytrace_batch([(0.5, 0.2, -3)], [(0, 0, 1)], sample=1)
+        fresh_n = build((0.1 * n, 0.05 * (n - 1), 4 + 0.1 * (n - 1)), (0, 30.0 + 2.0 * n + 0.5 * (n - 1), 0))
+        r3 = raytracing.Renderer(seed=5)
+        r3.init_render(raytracing.RenderSettings(fresh_n, 64, 36, 8, 4))
+        assert np.array_equal(L0, r3.raytrace_batch([(0.5, 0.2, -3)], [(0, 0, 1)], sample=1))
+        del L1
+
+    # render_area driven tile by tile, upstream's loop (all tiles, then the pass counter): every pass
+    # is a NEW sample, and the tiles add up to the whole-image render of the same passes.
+    r4 = raytracing.Renderer(seed=5)
+    r4.init_render(settings)
+    for _ in range(3):
+        for area in r4.divide_area(4, 2):
+            r4.render_area(area)
+        r4.render_result.rendered_passes += 1
+    r4.render_result.update_views()
+    r5 = raytracing.Renderer(seed=5)
+    r5.init_render(raytracing.RenderSettings(scene, 64, 36, 3, 4)); r5.render()
+    assert r4.render_result.rendered_pixels == 3 * 64 * 36
+    assert np.allclose(r4.render_result.arr, r5.render_result.arr, rtol=1e-6, atol=1e-6)
+    one = raytracing.Renderer(seed=5)
+    one.init_render(raytracing.RenderSettings(scene, 64, 36, 1, 4)); one.render()
+    assert np.abs(r4.render_result.arr - 3 * one.render_result.arr).max() > 0.05   # not one sample three times
+
 
 def test_parallelogram_rows_equal_triangle_rows(backend, monkeypatch):
     """Two triangles that share a diagonal are tested as one table row; the answers must be those of

@@ -292,3 +292,110 @@ def test_threaded_hierarchy_build_equals_single_threaded(monkeypatch):
     for threads in ("3", "8"):
         assert np.array_equal(out["1"][0], out[threads][0]) and np.array_equal(out["1"][1], out[threads][1])
     check_flat_bvh(out["8"][0], out["8"][1], tv)
+
+
+def test_scene_fingerprint_sees_every_setter_sequence():
+    """The change detector must not depend on array identities: the mesh setters free one array and
+    allocate the next, and CPython hands the same address out again, so id()-based keys come out
+    unchanged after a few setter calls.  Any number of setter calls between two looks must change
+    the fingerprint; no call must leave it alone."""
+    from raytracing_amd import raytracing
+    from raytracing_amd.core import Material, Vec3
+    from raytracing_amd.mesh import Mesh, Sphere
+
+    sc = raytracing.Scene()
+    m = Mesh(Material(Vec3(0.8), 0, 0, 0, 1.0), Vec3(0, 0, 3), [(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], [(0, 1, 2), (0, 2, 3)])
+    sc.add_object(m)
+    sc.add_object(Sphere(Material(Vec3(1), 1.0, 0, 0, 1.0), Vec3(0, 5, 3), 1.0))
+    seen = {sc.fingerprint()}
+    assert sc.fingerprint() in seen                      # stable without edits
+    for n in range(1, 9):
+        for trial in range(25):
+            for k in range(n):
+                which = (trial + k) % 3
+                if which == 0:
+                    m.set_origin(Vec3(0.01 * (trial + k), 0, 3))
+                elif which == 1:
+                    m.set_rotation(Vec3(0, 1.0 + trial + k, 0))
+                else:
+                    m.set_scale(Vec3(1.0 + 0.01 * (trial + k + 1)))
+            fp = sc.fingerprint()
+            assert fp not in seen, (n, trial)
+            seen.add(fp)
+    v0 = m.version
+    m.transformed_vertices = m.transformed_vertices.copy()   # direct assignment counts as an edit
+    m.triangles = [(0, 2, 1), (0, 3, 2)]
+    m.touch()
+    assert m.version == v0 + 3 and sc.fingerprint() not in seen
+
+    class ForeignMesh:   # a mesh-like object without a change counter (upstream's own class)
+        def __init__(self):
+            self.material = Material(Vec3(1), 0, 0, 0, 1.0)
+            self.origin, self.rotation, self.scale = Vec3(0), Vec3(0), Vec3(1)
+            self.transformed_vertices = [Vec3(0, 0, 0), Vec3(1, 0, 0), Vec3(0, 1, 0)]
+            self.triangles = [(0, 1, 2)]
+            self.bounding_box = (Vec3(0, 0, 0), Vec3(1, 1, 0))
+    f = ForeignMesh()
+    sc.add_object(f)
+    a = sc.fingerprint()
+    f.origin = Vec3(0, 0, 1)
+    f.bounding_box = (Vec3(0, 0, 1), Vec3(1, 1, 1))
+    assert sc.fingerprint() != a
+
+
+def test_app_loop_ends_when_the_render_thread_dies(monkeypatch):
+    """A library error on the background thread must not leave the poll loop spinning: the error is
+    kept on the result, the loop ends and run() raises; a stop request ends it without an error."""
+    import threading
+
+    from raytracing_amd import app, raytracing
+    from raytracing_amd.backend.lib import BackendError
+
+    class FakeBackend:
+        device = 0
+
+        def __init__(self, status):
+            self.status = status
+
+        def render(self, *a, **k):
+            raise BackendError(self.status, "injected")
+
+        def synchronize(self, *a):
+            pass
+
+        def stats(self):
+            return {}
+
+        def request_stop(self):
+            pass
+
+    def fake_start(self, settings, *a):
+        self.render_settings = settings
+        self.render_result = raytracing.RenderResult(settings.WIDTH, settings.HEIGHT, settings.RENDER_PASSES)
+        self.samples_per_launch = 1
+        self._backend = FakeBackend(fake_start.status)
+        self.start_executor(1, 1)
+        return self.render_result
+
+    monkeypatch.setattr(raytracing.Renderer, "start_render", fake_start)
+    settings = raytracing.RenderSettings(raytracing.Scene(), 8, 8, 4, 2)
+    done = {}
+
+    def go():
+        try:
+            done["ret"] = app.run(settings, poll_hz=500.0)
+        except RuntimeError as e:
+            done["err"] = e
+
+    for status, expect_error in ((3, True), (5, False)):   # RT_ERR_HIP, RT_ERR_STOPPED
+        fake_start.status = status
+        done.clear()
+        t = threading.Thread(target=go, daemon=True)
+        t.start()
+        t.join(10)
+        assert not t.is_alive(), "poll loop did not end"
+        if expect_error:
+            assert "err" in done and "injected" in str(done["err"])
+        else:
+            res, _ = done["ret"]
+            assert not res.finished and not res.failed and res.error is None
