@@ -165,8 +165,8 @@ int rt_create(int device_id, rt_ctx **out) {
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
     if (hipSetDevice(device_id) != hipSuccess || c->job_counter.ensure(256) != hipSuccess ||
-        c->stats.ensure(sizeof(unsigned long long) * kStatCount) != hipSuccess ||
-        hipMemset(c->stats.p, 0, sizeof(unsigned long long) * kStatCount) != hipSuccess) {
+        c->stats.ensure(sizeof(unsigned long long) * (kStatCount + kProfCount)) != hipSuccess ||
+        hipMemset(c->stats.p, 0, sizeof(unsigned long long) * (kStatCount + kProfCount)) != hipSuccess) {
         delete c;
         return fail(nullptr, RT_ERR_HIP, "device %d: initial allocation failed", device_id);
     }
@@ -902,6 +902,9 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     A.total_jobs = (uint32_t)total_jobs;
     A.div_rect_px = make_fast_div((uint32_t)rect_px); A.div_rect_h = make_fast_div((uint32_t)A.rect_h); A.job_counter = c->job_counter.as<uint32_t>(); A.accum = accum;
     A.stats = c->stats.as<unsigned long long>();
+#ifdef RT_SECTION_TIMERS
+    A.prof = A.stats + kStatCount;
+#endif
     if (n_chunks > 1) {
         // grows only; a larger request first drains work that may still read the old buffer
         size_t need = (size_t)total_jobs * 3 * sizeof(float);
@@ -967,12 +970,25 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     return RT_OK;
 }
 
+#ifdef RT_SECTION_TIMERS
+// Diagnostic builds only: wave cycles charged to each section of the render loop since rt_reset_stats.
+int rt_debug_section_cycles(rt_ctx *c, unsigned long long *out, int n) {
+    if (!c || !out) return RT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    unsigned long long v[kProfCount];
+    HIP_TRY(c, hipMemcpy(v, c->stats.as<unsigned long long>() + kStatCount, sizeof v, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < kProfCount; ++i) out[i] = v[i];
+    return RT_OK;
+}
+#endif
+
 int rt_reset_stats(rt_ctx *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     drain_events(c);
-    HIP_TRY(c, hipMemset(c->stats.p, 0, sizeof(unsigned long long) * kStatCount));
+    HIP_TRY(c, hipMemset(c->stats.p, 0, sizeof(unsigned long long) * (kStatCount + kProfCount)));
     { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms = 0; c->launches = 0; }
     return RT_OK;
 }

@@ -21,6 +21,25 @@
 
 namespace rt {
 
+// Section timers (diagnostic builds only: -DRT_SECTION_TIMERS).  PROF(k) charges the shader cycles
+// since the previous stamp of this wave to section k - one LDS add by one lane per stamp.  The
+// render kernel adds the per-wave totals to a global array at its end.  In ordinary builds PROF
+// compiles to nothing and no LDS is declared.
+enum { kProfHandout = 0, kProfBegin, kProfRaySetup, kProfSpheres, kProfBigSpheres, kProfQuadRows, kProfSlabRows, kProfTriRows,
+       kProfJudge, kProfSettle, kProfRecord, kProfSky, kProfDraws, kProfBounce, kProfAccum, kProfStats, kProfCount };
+#ifdef RT_SECTION_TIMERS
+__shared__ unsigned g_prof_acc[4][kProfCount];
+__shared__ unsigned g_prof_last[4];
+__device__ __noinline__ void prof_stamp_(int k) {
+    const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { g_prof_acc[w][k] += t - g_prof_last[w]; g_prof_last[w] = t; }
+}
+#define PROF(k) prof_stamp_(k)
+#else
+#define PROF(k) ((void)0)
+#endif
+
 RT_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 RT_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 RT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -415,11 +434,13 @@ RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
                 cur = next;
             }
         }
+        if (!Sink::kPerTriangle) PROF(kProfQuadRows);
         if (!Sink::kPerTriangle && S.slab_counts != 0) {
             const int nx = (int)(S.slab_counts & 1023u), ny = (int)((S.slab_counts >> 10) & 1023u), nz = (int)(S.slab_counts >> 20);
             slab_loop<0>(S.slab_rows, 0, nx, r, sink);
             slab_loop<1>(S.slab_rows, nx, ny, r, sink);
             slab_loop<2>(S.slab_rows, nx + ny, nz, r, sink);
+            PROF(kProfSlabRows);
         }
     }
     if (S.n_tri_rows_padded > 0) {
@@ -782,12 +803,15 @@ RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename Fi
     if (HAS_SPH) {
         if (pre != nullptr && S.n_sph_rows <= kFewSpheres) search_few_spheres(S, r, first, *pre, rel_accept, abs_accept);
         else search_spheres(S, r, first);
+        PROF(kProfSpheres);
         if (S.n_big_sph > 0) {
             const Ray64 x = ray64(r, rr);
             search_big_spheres(S, r, x.o, x.d, first);
         }
+        PROF(kProfBigSpheres);
     }
     if (TRI != kTriNone) search_tris(S, r, first);   // with a hierarchy: the few scene-sized triangles kept out of it
+    PROF(kProfTriRows);
 }
 
 // Everything after the first pass: judge the winner, settle what float32 could not, build the hit
@@ -828,6 +852,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
             status = v.status; t = v.t; thi = v.thi; gprim = S.n_spheres + v.ti; pair_open = v.open;
         }
     }
+    PROF(kProfJudge);
     const bool settle = route != kRouteFilter || (gprim >= 0 && (status != 0 || (has_second && !(second_lo > thi))));
     ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
     if (settle) {
@@ -880,6 +905,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         }
         h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
     }
+    PROF(kProfSettle);
     if (e64) *e64 = e;
     if (gprim < 0) return h;
     h.gprim = gprim;

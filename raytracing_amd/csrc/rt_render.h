@@ -238,12 +238,15 @@ RT_DEV RayResidue path_residue(SceneRef S, const float *ray_res, const Path &p) 
 // on; when it returns false (er, eg, eb) is the terminal radiance to be multiplied by (tr, tg, tb).
 RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float &er, float &eg, float &eb) {
     er = eg = eb = 0.0f;
+    PROF(kProfRecord);
     if (h.obj < 0) {
         environment(S, p.dx, p.dy, p.dz, er, eg, eb);
         return false;
     }
+    PROF(kProfSky);
     const MatRow m = S.materials[h.obj];
     const Draws u = segment_draws(p.key0, p.key1, (uint32_t)p.depth + 1u);
+    PROF(kProfDraws);
     bool alive = shade_bounce(m, h, u, p.dx, p.dy, p.dz, p.inside, p.tr, p.tg, p.tb, er, eg, eb);
     p.ox = h.px; p.oy = h.py; p.oz = h.pz; p.origin = h.gprim;
     p.depth++;
@@ -255,8 +258,11 @@ RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float
 template <int TRI, bool HAS_SPH>
 RT_DEV bool path_step(SceneRef S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h) {
     Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0);
+    PROF(kProfRaySetup);
     h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, path_residue(S, ray_res, p));
-    return path_shade(S, p, max_bounces, h, er, eg, eb);
+    const bool alive = path_shade(S, p, max_bounces, h, er, eg, eb);
+    PROF(kProfBounce);
+    return alive;
 }
 
 RT_DEV uint32_t fast_div(uint32_t n, const FastDiv &f) {
@@ -319,6 +325,12 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
     first.init(S);
     int walk_node = -1;
     bool walking = false;
+#ifdef RT_SECTION_TIMERS
+    if (lane_id() == 0) {
+        for (int k = 0; k < kProfCount; ++k) g_prof_acc[threadIdx.x >> 6][k] = 0;
+        g_prof_last[threadIdx.x >> 6] = (unsigned)__builtin_amdgcn_s_memtime();
+    }
+#endif
     KernargRenderArgs J = kernarg_render_args();
     ScenePtr Sp = kernarg_scene();
     // (spheres-only kernels measured 2 % faster with the plain by-value arguments)
@@ -370,6 +382,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
             idle = __ballot(!have_job);
         }
         if (__ballot(have_job) == 0) break;
+        PROF(kProfHandout);
 
         const bool starting = have_job && !in_path;
         w_paths += (uint32_t)__builtin_popcountll(__ballot(starting));
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                 path_begin(S, A.ray_dir, A.ray_res, p, p.pixel, (uint32_t)s_cur, A.seed_lo, A.seed_hi);
                 in_path = true;
             }
+            PROF(kProfBegin);
             // ---- 3. one path segment ----------------------------------------------------------
             float er = 0.0f, eg = 0.0f, eb = 0.0f;
             Hit h;
@@ -431,12 +445,18 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                 }
             }
         }
+        PROF(kProfAccum);
         w_rays += (uint32_t)__builtin_popcountll(__ballot(f_ray));
         w_exact += (uint32_t)__builtin_popcountll(__ballot(f_exact));
         w_refine += (uint32_t)__builtin_popcountll(__ballot(f_refine));
         w_sky += (uint32_t)__builtin_popcountll(__ballot(f_sky));
         w_shaded += (uint32_t)__builtin_popcountll(__ballot(f_shaded));
+        PROF(kProfStats);
     }
+#ifdef RT_SECTION_TIMERS
+    if (lane_id() == 0 && A.prof != nullptr)
+        for (int k = 0; k < kProfCount; ++k) atomicAdd(A.prof + k, (unsigned long long)g_prof_acc[threadIdx.x >> 6][k]);
+#endif
     // ---- statistics: one atomic per counter per wave ------------------------------------------
     unsigned long long nodes = bc.nodes, tris = bc.tris;
     if (TRI == kTriBvh) {

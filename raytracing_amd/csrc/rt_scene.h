@@ -142,6 +142,7 @@ struct RenderArgs {
     float *accum;             // (W,H,3) running sum
     float *partial;           // [n_chunks][rect_w*rect_h][3] when n_chunks > 1, else unused
     unsigned long long *stats;  // kStat* counters
+    unsigned long long *prof;   // section-timer totals (diagnostic builds with RT_SECTION_TIMERS), else null
 };
 
 enum { kStatRays = 0, kStatPaths, kStatSphTests, kStatTriTests, kStatExact, kStatRefine, kStatSky, kStatShaded,

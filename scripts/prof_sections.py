@@ -1,0 +1,28 @@
+"""Section timers of the render loop (developer tool; needs a library built with -DRT_SECTION_TIMERS:
+    hipcc <flags of raytracing_amd/backend/build.py> -DRT_SECTION_TIMERS -o build_ab/_rt_hip_prof.so raytracing_amd/csrc/rt_api.hip
+    RAYTRACING_AMD_LIB=build_ab/_rt_hip_prof.so python scripts/prof_sections.py [scene] [spp])."""
+import ctypes as C, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+import helpers as h
+from raytracing_amd.backend.lib import HipBackend
+NAMES = ["handout", "begin", "ray_setup", "spheres", "big_spheres", "quad_rows", "slab_rows", "tri_rows", "judge", "settle",
+         "record", "sky", "draws", "bounce", "accum", "stats"]
+name = sys.argv[1] if len(sys.argv) > 1 else "room"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+be = HipBackend(0)
+be.set_scene(h.packed_scene(name))
+W, H = 1920, 1080
+be.resize(W, H)
+be.render(W, H, 0, 4, 8, 1); be.synchronize()
+be.reset_stats()
+be.render(W, H, 0, spp, 8, 1); be.synchronize()
+st = be.stats()
+out = (C.c_uint64 * 16)()
+be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+be.lib.rt_debug_section_cycles(be.handle, out, 16)
+tot = sum(out)
+iters = st["rays"] / 64.0
+print(f"{name} {spp} spp: kernel {st['kernel_ms']:.2f} ms, rays {st['rays']}, wave-iterations {iters:.3e}, cycles/iteration (wave view) {tot / iters:.0f}")
+for n, v in zip(NAMES, out):
+    print(f"  {n:12s} {100.0 * v / tot:6.2f} %   {v / iters:8.1f} cycles / iteration")
