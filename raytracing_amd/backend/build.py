@@ -15,7 +15,7 @@ SOURCES = ["rt_api.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "raytracing_amd.h")]
 # -ffp-contract=off: the double-precision exact code must round like upstream's Python floats (no
 # fused multiply-add); the float32 kernels spell out every fma explicitly.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wno-pass-failed"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-pthread", "-Wno-pass-failed"]
 
 
 def needs_build() -> bool:

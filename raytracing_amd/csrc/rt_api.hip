@@ -336,7 +336,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         double nl = norm(N);
         TriRow r{}; TriAux x{};
         const int m = tri_mesh[t];
-        x.obj = d->mesh_obj[m]; x.face = t - d->mesh_tri_begin[m]; x.mesh = m; x.pair_row = -1;
+        x.obj = d->mesh_obj[m]; x.face = t - d->mesh_tri_begin[m]; x.tag = 0.0f; x.pair_row = -1;
         r.gprim = d->n_spheres + t;
         // |det| = |d.N| <= |d||N|: with |d| <= 2 (longer rays use the exact code) a triangle with
         // |N| < 4e-7 can never pass upstream's |det| >= 1e-6 cut, nor can a non-finite one.
@@ -455,6 +455,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
                 r.gprim = kQuadFlag | ((d->n_spheres + y) << kQuadIdBits) | (d->n_spheres + t);
                 taken[y] = 1;
                 ++n_live_tris;
+                aux[t].tag = (float)(d->n_spheres + t + 1); aux[y].tag = -(float)(d->n_spheres + t + 1);   // ids < 8192: exact
                 aux[t].det_hi = aux[y].det_hi = std::max(aux[t].det_hi, aux[y].det_hi);
                 int axis = -1;
                 if (N.y == 0 && N.z == 0) axis = 0; else if (N.x == 0 && N.z == 0) axis = 1; else if (N.x == 0 && N.y == 0) axis = 2;
@@ -470,20 +471,27 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         }
     }
     // Parallelogram rows in general position first, then those in axis-perpendicular planes (by axis);
-    // the latter also get their compact form.  At most 1023 per axis (the counts share one word).
+    // the latter also get their compact form.  At most 1022 live ones per axis (the counts share one word, and an axis is padded to an even count).
     std::vector<SlabRow> rows_slab;
     int n_quad_general = 0;
     uint32_t slab_counts = 0;
     {
         int per_axis[3] = {0, 0, 0};
-        for (auto &pi : pair_info) if (pi.axis >= 0 && ++per_axis[pi.axis] > 1023) { pi.axis = -1; }
+        for (auto &pi : pair_info) if (pi.axis >= 0 && ++per_axis[pi.axis] > 1022) { pi.axis = -1; }
         std::vector<int> order;
         for (int pass = -1; pass < 3; ++pass)
             for (int k = 0; k < (int)pair_info.size(); ++k) if (pair_info[k].axis == pass) order.push_back(k);
         std::vector<TriRow> sorted(rows_quad.size());
         int counts[3] = {0, 0, 0};
+        // the dead compact row: vq = -inf, so it is never inside; no origin tag equals its idf
+        SlabRow dead_slab{}; dead_slab.k2h = -INFINITY; dead_slab.idf = -5.0f; dead_slab.gprim = kQuadFlag;
+        int last_axis = -1;
+        auto close_axis = [&](int axis) {   // the compact-row loop takes two rows per trip: every axis holds an even number
+            if (axis >= 0 && counts[axis] % 2) { rows_slab.push_back(dead_slab); ++counts[axis]; }
+        };
         for (int k = 0; k < (int)order.size(); ++k) {
             const PairInfo &pi = pair_info[order[k]];
+            if (pi.axis != last_axis) { close_axis(last_axis); last_axis = pi.axis; }
             const TriRow &q = rows_quad[order[k]];
             sorted[k] = q;
             aux[pi.tri].pair_row = k;
@@ -493,17 +501,24 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             sr.c0 = (float)pi.c0;
             const float e1[3] = {q.e1x, q.e1y, q.e1z}, e2[3] = {q.e2x, q.e2y, q.e2z};
             const int b = pi.axis == 0 ? 1 : 0, cc = pi.axis == 2 ? 1 : 2;
-            sr.e1b = e1[b]; sr.e1c = e1[cc]; sr.k1 = q.k1; sr.e2b = e2[b]; sr.e2c = e2[cc]; sr.k2 = q.k2;
-            // bound constants for a unit normal: the general row's divided by |N|
-            sr.cb = up(1.000001 * (double)q.cb / pi.nl);
+            // centred coordinates: vq = v - 1/2, sq = u + v - 1/2 (see SlabRow)
+            sr.e2b = e2[b]; sr.e2c = e2[cc]; sr.k2h = (float)((double)q.k2 - 0.5);
+            sr.esb = (float)((double)e1[b] + (double)e2[b]); sr.esc = (float)((double)e1[cc] + (double)e2[cc]);
+            sr.ksh = (float)((double)q.k1 + (double)q.k2 - 0.5);
+            // bound constants for a unit normal: the general row's divided by |N|; the barycentric one
+            // also takes the rounding of the two shifted constants and of 1/2 - max(|vq|, |sq|), about
+            // 1.5 u in all: the depth-error scale is at least 2 u S, S >= scene radius, so 2 / S_min covers it
+            sr.cb = up(1.000001 * ((double)q.cb / pi.nl + 2.0 / std::max(scene_radius, 1e-30)));
             sr.ct = up(1.000001 * (double)q.ct / pi.nl);
-            sr.det_lo = (float)((double)q.det_lo / pi.nl) * (1.0f - 4.0f * kU);
+            sr.id1 = q.gprim & ((1 << kQuadIdBits) - 1);
+            sr.idf = (float)(sr.id1 + 1);
             sr.gprim = q.gprim;
             rows_slab.push_back(sr);
         }
+        close_axis(last_axis);
         rows_quad.swap(sorted);
         slab_counts = (uint32_t)counts[0] | ((uint32_t)counts[1] << 10) | ((uint32_t)counts[2] << 20);
-        if (!rows_slab.empty()) { SlabRow dead{}; dead.k1 = dead.k2 = -1; dead.det_lo = INFINITY; dead.gprim = kQuadFlag; rows_slab.push_back(dead); }
+        if (!rows_slab.empty()) rows_slab.push_back(dead_slab);   // the row the loops may read ahead into
     }
     // ---- materials, environment ---------------------------------------------------------------
     std::vector<MatRow> mats(d->n_objects);
@@ -599,6 +614,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     HIP_TRY(c, c->cold.upload(std::vector<ColdScene>{cold}));
     S.cold = c->cold.as<ColdScene>();
     S.n_spheres = d->n_spheres;
+    S.n_prims = (int32_t)n_gprim;
     S.scene_radius = up(scene_radius * 1.000001);
     int bits = 5;
     while ((1ll << bits) < n_gprim && bits < 23) ++bits;   // only the linear walk's 32-bit keys use it
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(256) void k_intersect(const DevScene S_arg, const I
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.how = 2; h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0;
     bool did_exact = false;
     if (f32_ray) {
-        Ray r = make_ray(S, fox, foy, foz, fdx, fdy, fdz, origin, false);
+        Ray r = make_ray(S, fox, foy, foz, fdx, fdy, fdz, origin, false, origin_tag(S, origin));
         h = closest_hit<TRI, HAS_SPH, true>(S, r, &e, no_residue());
         did_exact = h.how == 2;
     } else {

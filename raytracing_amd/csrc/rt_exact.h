@@ -117,7 +117,7 @@ RT_DEV ExactHit exact_single(SceneRef S, int32_t gprim, D3 o, D3 d, int32_t orig
     int32_t ti = gprim - S.n_spheres;
     ExactHit miss; miss.hit = false; miss.prim = 0; miss.t = 0; miss.n = d3(0, 0, 0); miss.pos = miss.n;
     if (gprim == origin) return miss;
-    if (!exact_aabb(C.aabb64 + 6 * (size_t)S.tri_aux[ti].mesh, o, d)) return miss;
+    if (!exact_aabb(C.aabb64 + 6 * (size_t)C.obj_index[S.tri_aux[ti].obj], o, d)) return miss;
     return exact_tri(C.tri64 + 9 * (size_t)ti, o, d);
 }
 
@@ -133,7 +133,7 @@ RT_DEV ExactDepth exact_single_depth(SceneRef S, int32_t gprim, D3 o, D3 d, int3
     else {
         const int32_t ti = gprim - S.n_spheres;
         if (gprim == origin) return r;
-        if (!exact_aabb(C.aabb64 + 6 * (size_t)S.tri_aux[ti].mesh, o, d)) return r;
+        if (!exact_aabb(C.aabb64 + 6 * (size_t)C.obj_index[S.tri_aux[ti].obj], o, d)) return r;
         h = exact_tri(C.tri64 + 9 * (size_t)ti, o, d, false);
     }
     r.hit = h.hit; r.t = h.t;

@@ -93,12 +93,12 @@ RT_DEV SlabRow load_slab_row_uniform(const SlabRow *rows, int i) {
     const_f4_ptr q = as_const_f4(rows) + 3 * (size_t)i;
     f4 a = q[0], b = q[1], c = q[2];
     SlabRow T;
-    T.c0 = a.x; T.e1b = a.y; T.e1c = a.z; T.k1 = a.w;
-    T.e2b = b.x; T.e2c = b.y; T.k2 = b.z; T.cb = b.w;
-    T.ct = c.x; T.det_lo = c.y;
-    const float id_bits = c.z;
-    T.gprim = (int32_t)f2u(id_bits);
-    T.pad = 0;
+    T.c0 = a.x; T.e2b = a.y; T.e2c = a.z; T.k2h = a.w;
+    T.esb = b.x; T.esc = b.y; T.ksh = b.z; T.cb = b.w;
+    T.ct = c.x; T.idf = c.y;
+    const float id_bits = c.z, word_bits = c.w;
+    T.id1 = (int32_t)f2u(id_bits);
+    T.gprim = (int32_t)f2u(word_bits);
     return T;
 }
 
@@ -129,12 +129,20 @@ struct Ray {
     float c4, c7;          // triangle bounds: q = c7 |t| + c4 with c4 = 4u S, c7 = 7u |d|, S = |o| + scene_radius
     float band0;           // crude per-ray discriminant bound for the in-loop sphere test
     int32_t origin;        // global id of the primitive the ray starts on, -1 = none
+    // The same fact in the form the compact parallelogram rows test it (TriAux::tag of the origin):
+    float own_idf;         // |tag| = (float)(id + 1) of the first triangle of the origin's row, 0 = the origin heads no such row
+    float own_sign;        // +1: the origin is that first triangle (the side u > 0), -1: the second
 };
+
+// TriAux::tag of the primitive a ray starts on (0 for none, a sphere, or a triangle in no parallelogram row).
+RT_DEV float origin_tag(SceneRef S, int32_t origin) {
+    return (origin >= S.n_spheres && origin < S.n_prims) ? S.tri_aux[origin - S.n_spheres].tag : 0.0f;
+}
 
 // `rounded` = the ray is the float32 rounding of a double-precision ray the exact code will use
 // (camera rays): every bound then also covers u per component of o and d.
 RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy, float dz, int32_t origin,
-                    bool rounded) {
+                    bool rounded, float tag) {
     Ray r;
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.a = fma_(dz, dz, fma_(dy, dy, dx * dx));
@@ -147,6 +155,8 @@ RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy
     r.c7 = 7.0f * k * r.dlen;
     r.band0 = 72.0f * kU * r.a * Sr * Sr;
     r.origin = origin;
+    r.own_idf = abs_(tag);
+    r.own_sign = tag < 0.0f ? -1.0f : 1.0f;
     return r;
 }
 
@@ -377,43 +387,96 @@ RT_DEV void quad_row_candidates(const TriRow &T, const Ray &r, Sink &sink) {
     }
 }
 
-// The same parallelogram test for a row in a plane perpendicular to axis AXIS (SlabRow): the general
-// row's arithmetic with N = the axis unit vector, so every bound of the error model above holds with
-// room to spare (N.d is exact, N.o + kN is one subtraction).  `inv` = 1 / d_AXIS, once per ray.
+RT_DEV float min3_(float a, float b, float c) { return min_(min_(a, b), c); }
+RT_DEV float max3_(float a, float b, float c) { return max_(max_(a, b), c); }
+
+// Per ray and axis, what every compact row of that axis shares.
+struct SlabRay {
+    float ob, db, oc, dc;   // the ray in the plane's two free coordinates
+    float inv, noi;         // 1 / d_a and -o_a / d_a:  t = c0 * inv + noi
+    float c4i, c7i;         // the depth-error scale g = c7i |t| + c4i  ( = (c7 |t| + c4) / |d_a| )
+};
+
 template <int AXIS>
-RT_DEV RowEval slab_eval(const SlabRow &T, const Ray &r, float inv) {
+RT_DEV SlabRay slab_ray(const Ray &r) {
     const float oa = AXIS == 0 ? r.ox : (AXIS == 1 ? r.oy : r.oz), da = AXIS == 0 ? r.dx : (AXIS == 1 ? r.dy : r.dz);
-    const float ob = AXIS == 0 ? r.oy : r.ox, db = AXIS == 0 ? r.dy : r.dx;
-    const float oc = AXIS == 2 ? r.oy : r.oz, dc = AXIS == 2 ? r.dy : r.dz;
-    RowEval e;
-    const float t = (T.c0 - oa) * inv;
-    const float pb = fma_(t, db, ob), pc = fma_(t, dc, oc);
-    e.u = fma_(T.e1c, pc, fma_(T.e1b, pb, T.k1));
-    e.v = fma_(T.e2c, pc, fma_(T.e2b, pb, T.k2));
-    e.w = (1.0f - e.u) - e.v;
-    const float g = fma_(r.c7, abs_(t), r.c4) * abs_(inv);
-    e.bb = g * T.cb;
-    e.t = t;
-    e.thi = fma_(g, T.ct, t);
-    e.tlo = fma_(-g, T.ct, t);
-    e.nd_abs = abs_(da);
-    // Upstream's |det| cut (mesh.py:123) is left to the judge here: a row below it has |d_a| < ~1e-6,
-    // its depth is huge, and if it ever wins, the winner's re-evaluation refuses it (det_hi) and the
-    // double-precision code settles the ray.  Padding rows are never evaluated by slab_loop.
-    e.dead = false;
-    return e;
+    SlabRay a;
+    a.ob = AXIS == 0 ? r.oy : r.ox; a.db = AXIS == 0 ? r.dy : r.dx;
+    a.oc = AXIS == 2 ? r.oy : r.oz; a.dc = AXIS == 2 ? r.dy : r.dz;
+    a.inv = rcp_(da);
+    a.noi = -(oa * a.inv);
+    const float ai = abs_(a.inv);
+    a.c4i = r.c4 * ai; a.c7i = r.c7 * ai;
+    return a;
 }
 
+// One compact row as ONE candidate (the parallelogram test of pair_candidate for a plane perpendicular
+// to a coordinate axis): the general row's arithmetic with N = the axis unit vector, so every bound
+// of the error model above holds with room to spare (N.d is exact; t = c0 * inv + noi carries
+// 2u |t| + u |o_a / d_a|, inside the model's 4u S / |d_a| + 7u |t|).  18 full-rate and 6 half-rate
+// vector instructions, no scalar ones, no select:
+//   * inside test on the centred coordinates: margin + band = band + (1/2 - max(|vq|, |sq|));
+//   * the ray-origin rule (a ray that starts on one of the row's two triangles cannot hit that one
+//     again: the row is out when the crossing point is clearly on the origin's side of the diagonal)
+//     is arithmetic too: with z = |idf - own_idf| * 1e30 (0 for the origin's own row, >= 1e30 for any
+//     other) and k = u * own_sign - band, the row is out exactly when k - z > 0, and -(k - z) simply
+//     joins the minimum whose sign decides candidacy.  A NaN anywhere drops out of min / max and
+//     keeps the candidate, as everywhere in this filter.
+// Upstream's |det| cut (mesh.py:123) is left to the judge: a row below it has |d_a| < ~1e-6, its
+// depth is huge, and if it ever wins, the winner's re-evaluation refuses it (det_hi) and the
+// double-precision code settles the ray.
+template <class Sink>
+RT_DEV void slab_row_test(const SlabRow &T, const SlabRay &a, const Ray &r, Sink &sink) {
+    const float t = fma_(T.c0, a.inv, a.noi);
+    const float pb = fma_(t, a.db, a.ob), pc = fma_(t, a.dc, a.oc);
+    const float vq = fma_(T.e2c, pc, fma_(T.e2b, pb, T.k2h));
+    const float sq = fma_(T.esc, pc, fma_(T.esb, pb, T.ksh));
+    const float g = fma_(a.c7i, abs_(t), a.c4i);
+    const float thi = fma_(g, T.ct, t), tlo = fma_(-g, T.ct, t);
+    const float bb = g * T.cb;
+    const float mpb = bb + (0.5f - max_(abs_(vq), abs_(sq)));
+    const float k = fma_(sq - vq, r.own_sign, -bb);
+    const float q = fma_(-abs_(T.idf - r.own_idf), 1e30f, k);
+    const float x = min3_(mpb, thi, -q);
+    const float y = x * (-kInf);                 // x < 0 -> +inf (not a candidate); x >= 0 -> -inf / NaN
+    sink(max3_(tlo, 0.0f, y), T.id1);
+}
+
+// The rows of one axis, two per trip from two sets of scalar registers that take turns (copying
+// "next" into "current" instead would cost eight scalar moves per row, and a scalar instruction
+// takes an issue slot like a vector one).  Every axis holds an EVEN number of rows (the host pads
+// with a dead row), so a trip is one basic block: with a branch between the two tests the compiler
+// sinks the second row's loads below it, to just before their first use, and every wave then sits
+// out the scalar-memory latency once per row.  The scheduling barriers keep each load where it is
+// written, a full row test ahead of its use.  (The loads stay ordinary loads the compiler tracks:
+// it places the wait before the first use and never copies or spills a register whose load is
+// still in flight - hand-issued loads in inline assembly give no such guarantee.)  The table ends
+// with a dead row, so reading one row ahead is always in bounds.
 template <int AXIS, class Sink>
 RT_DEV void slab_loop(const SlabRow *rows, int begin, int n, const Ray &r, Sink &sink) {
     if (n <= 0) return;
-    const float inv = rcp_(AXIS == 0 ? r.dx : (AXIS == 1 ? r.dy : r.dz));
-    SlabRow cur = load_slab_row_uniform(rows, begin);
-    for (int i = 0; i < n; ++i) {
-        const SlabRow next = load_slab_row_uniform(rows, begin + i + 1);   // the table ends with a dead row
-        pair_candidate(slab_eval<AXIS>(cur, r, inv), cur.gprim, r, sink);
-        cur = next;
-    }
+    const SlabRow *p = rows + begin;
+    SlabRow A = load_slab_row_uniform(p, 0);
+    const SlabRay a = slab_ray<AXIS>(r);
+    do {
+        // Scalar loads come back in any order, so the only wait there is waits for all of them: each
+        // row's loads are therefore issued BEHIND the wait for the row about to be tested.  The empty
+        // asm statements do that: they need the landed row's first word (which places the wait), and
+        // the address of the loads that follow is their output (which keeps those loads from being
+        // merged with earlier ones or hoisted above the wait).
+        const SlabRow *pb = p + 1;
+        asm volatile("" : "+s"(pb) : "s"(A.c0));
+        const SlabRow B = load_slab_row_uniform(pb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slab_row_test(A, a, r, sink);
+        __builtin_amdgcn_sched_barrier(0);
+        p += 2;
+        asm volatile("" : "+s"(p) : "s"(B.c0));
+        A = load_slab_row_uniform(p, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slab_row_test(B, a, r, sink);
+        n -= 2;
+    } while (n > 0);
 }
 
 // Brute-force loops over the two linear tables (parallelogram rows, then triangle rows), two rows
@@ -724,6 +787,7 @@ RT_DEV void search_few_spheres(SceneRef S, const Ray &r, Sink &sink, SpherePre &
 struct Hit {
     int32_t obj, prim, gprim;   // obj < 0: miss
     float t, nx, ny, nz, px, py, pz;
+    float tag;                  // TriAux::tag of the hit triangle (0 for a sphere): what the next ray's origin test needs
     int32_t how;                // 0 float32 filter alone, 1 winner re-evaluated in double, 2 contenders / scene settled in double
     bool refined;               // the winning primitive was re-evaluated in double precision on the way
     uint32_t bvh_nodes, bvh_tris;   // boxes and triangles this query tested in the hierarchy (0 without one)
@@ -820,7 +884,7 @@ RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename Fi
 template <int TRI, bool HAS_SPH, bool STRICT>
 RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
                       BvhCounters bc, ExactHit *e64, const SpherePre *pre = nullptr) {
-    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0;
+    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0; h.tag = 0.0f;
     h.refined = false; h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
     const int route = ray_route<TRI>(r);
     int32_t gprim = -1; int root = 0; float t = kInf;
@@ -829,7 +893,9 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
     // absolute depth tolerance of the render kernel (see kAbsAcceptRender); none for the closest-hit entry
     const float abs_accept = STRICT ? 0.0f : kAbsAcceptRender * (r.o2 + S.scene_radius);
     if (route == kRouteFilter && first.any()) {
-        gprim = first.best_id();
+        // (clamped: a corrupted key must never turn into an out-of-bounds table index - a wrong answer
+        // shows up in the parity tests, a wild read takes the GPU down)
+        gprim = (int32_t)umin_((uint32_t)first.best_id(), (uint32_t)(S.n_prims - 1));
         second_lo = first.second_lo();
         has_second = first.has_second();
         if (gprim < S.n_spheres) {
@@ -913,7 +979,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         h.obj = S.sph_obj[gprim]; h.prim = e.hit ? e.prim : root;
     } else {
         const TriAux A = S.tri_aux[gprim - S.n_spheres];
-        h.obj = A.obj; h.prim = A.face;
+        h.obj = A.obj; h.prim = A.face; h.tag = A.tag;
     }
     if (e.hit) {
         if (h.how == 0) h.how = 1;

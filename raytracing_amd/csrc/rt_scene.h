@@ -29,14 +29,22 @@ struct TriRow {
 
 // A parallelogram row whose plane is perpendicular to a coordinate axis a (walls, floors, box faces),
 // in compact form, 12 dwords: t = (c0 - o_a) / d_a needs no dot products and shares one reciprocal
-// per ray and axis; (b, c) are the other two axes in increasing order, u = e1b p_b + e1c p_c + k1,
-// v likewise.  Bound constants as in TriRow, for a unit plane normal.
+// per ray and axis; (b, c) are the other two axes in increasing order.  The two functionals are
+// CENTRED coordinates of the crossing point p in the parallelogram, in the first triangle's
+// barycentrics (u = weight of b, v = weight of c):
+//     vq = v - 1/2     = e2b p_b + e2c p_c + k2h
+//     sq = u + v - 1/2 = esb p_b + esc p_c + ksh
+// so that the point is inside exactly when max(|vq|, |sq|) <= 1/2 (one instruction with free
+// absolute-value modifiers instead of four subtractions and two minima), and u = sq - vq names the
+// triangle.  Bound constants as in TriRow, for a unit plane normal; cb also covers the rounding of
+// the two shifted constants and of 1/2 - max.
 struct SlabRow {
-    float c0, e1b, e1c, k1;
-    float e2b, e2c, k2, cb;
-    float ct, det_lo;   // det_lo: |d_a| below this can never pass upstream's |det| cut
+    float c0, e2b, e2c, k2h;
+    float esb, esc, ksh, cb;
+    float ct;
+    float idf;          // (float)(id1 + 1): lets the ray-origin test be arithmetic (see slab_row_test)
+    int32_t id1;        // the first triangle's id = the id the row's candidate carries
     int32_t gprim;      // id word of the parallelogram row (see kQuadFlag)
-    int32_t pad;
 };
 
 // Data needed once a triangle has won: unit normal (mesh.py:140), owner, certain-accept cut.
@@ -45,7 +53,8 @@ struct TriAux {
     float det_hi;       // |N.d| at or above this certainly passes the 1e-6 cut
     int32_t obj;        // index into scene.objects
     int32_t face;       // face index inside its mesh
-    int32_t mesh;       // mesh index (for the bounding-box gate of the exact code)
+    float tag;          // ray-origin tag: +(id + 1) of the first triangle of this triangle's parallelogram row when it is
+                        // that first triangle, -(id + 1) when it is the second; 0 for a triangle in no such row
     int32_t pair_row;   // index into quad_rows of the parallelogram row this triangle heads (it is the row's first), else -1
 };
 
@@ -104,6 +113,7 @@ struct DevScene {
                                                       // ray-direction octant, each with its top levels first; 0 = none
     int32_t n_top_nodes;                              // per copy, the first n_top_nodes nodes are the top levels (staged in LDS)
     int32_t n_spheres;
+    int32_t n_prims;          // n_spheres + number of triangles: candidate ids are clamped below it before they index a table
     float scene_radius;       // bound on the distance from the world origin of every vertex, small-sphere point and the camera
     uint32_t key_mask;        // low bits of a hit key that hold the primitive id
     // camera: float32 position and its double-precision residue (pinhole rays come from k_raygen's table)
