@@ -104,6 +104,7 @@ struct rt_ctx {
     std::vector<EventPair> timed;        // recorded around render launches, not yet read
     std::vector<EventPair> spare_events; // read and ready for reuse (events are created once, not per launch)
     double kernel_ms = 0; uint64_t launches = 0;
+    uint64_t paths_launched = 0;         // paths of rt_render's single-kernel launches: rectangle x samples, known here, not counted on the device
 };
 
 namespace {
@@ -945,7 +946,7 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
         hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((rect_px + 255) / 256)), dim3(256), 0, stream, A);
         HIP_TRY(c, hipGetLastError());
     }
-    { std::lock_guard<std::mutex> g(c->mu); c->timed.push_back(ev); c->launches++; }
+    { std::lock_guard<std::mutex> g(c->mu); c->timed.push_back(ev); c->launches++; c->paths_launched += (uint64_t)rect_px * (uint64_t)p->sample_count; }
     return RT_OK;
 }
 
@@ -982,7 +983,7 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     out->rays = v[kStatRays]; out->paths = v[kStatPaths]; out->sphere_tests = v[kStatSphTests]; out->tri_tests = v[kStatTriTests];
     out->aabb_tests = 0; out->bvh_node_tests = v[kStatBvhNodes]; out->exact_rays = v[kStatExact]; out->refined_hits = v[kStatRefine];
     out->sky_lookups = v[kStatSky]; out->shaded_hits = v[kStatShaded];
-    { std::lock_guard<std::mutex> g(c->mu); out->kernel_ms = c->kernel_ms; out->launches = c->launches; }
+    { std::lock_guard<std::mutex> g(c->mu); out->kernel_ms = c->kernel_ms; out->launches = c->launches; out->paths += c->paths_launched; }
     return RT_OK;
 }
 
@@ -1005,7 +1006,7 @@ int rt_reset_stats(rt_ctx *c) {
     HIP_TRY(c, hipDeviceSynchronize());
     drain_events(c);
     HIP_TRY(c, hipMemset(c->stats.p, 0, sizeof(unsigned long long) * (kStatCount + kProfCount)));
-    { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms = 0; c->launches = 0; }
+    { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms = 0; c->launches = 0; c->paths_launched = 0; }
     return RT_OK;
 }
 

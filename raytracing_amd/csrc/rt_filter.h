@@ -161,8 +161,14 @@ RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy
 }
 
 RT_DEV bool ray_needs_exact(const Ray &r) {
-    bool ok = (r.a >= 0.25f) && (r.a <= 4.0f) && (r.dx != 0.0f) && (r.dy != 0.0f) && (r.dz != 0.0f);
-    return !(ok && r.o2 < 1e18f);
+    // the filter takes the ray when 1/4 <= d.d <= 4, no component of d is zero and |o| < 1e18: the
+    // smallest of three margins is positive (one compare instead of six and their mask arithmetic;
+    // a NaN or infinity anywhere fails the compare and sends the ray to the exact code)
+    const float m = min_(min_(abs_(r.dx), abs_(r.dy)), abs_(r.dz));
+    const float in_range = 1.875f - abs_(r.a - 2.125f);   // >= 0 exactly when 1/4 <= d.d <= 4
+    const float q = min_(min_(m, in_range + 1e-30f), 1e18f - r.o2);
+    // (min drops a NaN operand: 0 * (d.d + |o|) puts a NaN or an infinity back into the compare)
+    return !(fma_(0.0f, r.a + r.o2, q) > 0.0f);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -168,9 +168,10 @@ RT_DEV void camera_ray(SceneRef S, const float *ray_dir, const float *ray_res, u
 // they are consumed positionally, so skipping U1 shifts the rest down by one.
 RT_DEV bool shade_bounce(const MatRow &m, const Hit &h, const Draws &u, float &dx, float &dy, float &dz,
                          bool &inside, float &tr, float &tg, float &tb, float &er, float &eg, float &eb) {
-    float nx = h.nx, ny = h.ny, nz = h.nz;
-    float eta = rcp_(m.ior);
-    if (inside) { nx = -nx; ny = -ny; nz = -nz; eta = m.ior; }
+    // (sign flips are exclusive-ors of the sign bit: full-rate instructions, where a select runs at half rate)
+    const uint32_t flip = inside ? 0x80000000u : 0u;
+    const float nx = u2f(f2u(h.nx) ^ flip), ny = u2f(f2u(h.ny) ^ flip), nz = u2f(f2u(h.nz) ^ flip);
+    const float eta = inside ? m.ior : rcp_(m.ior);
     if (m.emission > 0.0f) {
         er = m.r * m.emission; eg = m.g * m.emission; eb = m.b * m.emission;
         return false;
@@ -193,8 +194,11 @@ RT_DEV bool shade_bounce(const MatRow &m, const Hit &h, const Draws &u, float &d
             float rx = (tir ? u.f1 : u.f2) * 2.0f - 1.0f, ry = (tir ? u.f2 : u.f3) * 2.0f - 1.0f, rz = (tir ? u.f3 : u.f4) * 2.0f - 1.0f;
             float s = rsq_(fma_(rz, rz, fma_(ry, ry, rx * rx)));
             rx *= s; ry *= s; rz *= s;
-            if (fma_(rz, nz, fma_(ry, ny, rx * nx)) < 0.0f) { rx = -rx; ry = -ry; rz = -rz; }
-            dx = rx; dy = ry; dz = rz;
+            // into the normal's hemisphere (util.py:33-34: negated when the dot product is below zero; a
+            // dot product of -0.0 leaves upstream's sample as it is, so the sign bit alone will not do)
+            const float dn2 = fma_(rz, nz, fma_(ry, ny, rx * nx));
+            const uint32_t sgn = dn2 < 0.0f ? 0x80000000u : 0u;
+            dx = u2f(f2u(rx) ^ sgn); dy = u2f(f2u(ry) ^ sgn); dz = u2f(f2u(rz) ^ sgn);
         }
     } else {   // refract (util.py:18-22): result is not normalised
         float cr = min_(cs, 1.0f);
@@ -237,10 +241,13 @@ RT_DEV RayResidue path_residue(SceneRef S, const float *ray_res, const Path &p) 
 
 // What follows a closest-hit answer: environment or one bounce.  Returns true while the path goes
 // on; when it returns false (er, eg, eb) is the terminal radiance to be multiplied by (tr, tg, tb).
-RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float &er, float &eg, float &eb) {
+// `sky_count` is the calling lane's own count of environment lookups: one add inside the branch that
+// runs anyway, instead of a flag, a compare and a ballot per trip; the kernel sums the lanes at its end.
+RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float &er, float &eg, float &eb, uint32_t &sky_count) {
     er = eg = eb = 0.0f;
     PROF(kProfRecord);
     if (h.obj < 0) {
+        sky_count += 1u;
         environment(S, p.dx, p.dy, p.dz, er, eg, eb);
         return false;
     }
@@ -257,11 +264,12 @@ RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float
 
 // One segment: closest hit, then environment or one bounce.
 template <int TRI, bool HAS_SPH>
-RT_DEV bool path_step(SceneRef S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h) {
+RT_DEV bool path_step(SceneRef S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h,
+                      uint32_t &sky_count) {
     Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag);
     PROF(kProfRaySetup);
     h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, path_residue(S, ray_res, p));
-    const bool alive = path_shade(S, p, max_bounces, h, er, eg, eb);
+    const bool alive = path_shade(S, p, max_bounces, h, er, eg, eb, sky_count);
     PROF(kProfBounce);
     return alive;
 }
@@ -308,7 +316,8 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
     p.depth = 0; p.origin = -1; p.tag = 0.0f; p.inside = false; p.pixel = 0;
     // Statistics are kept per WAVE in scalar registers (lane counts of ballots taken where the wave
     // is converged), not per lane: six vector registers less for the whole life of the kernel.
-    uint32_t w_rays = 0, w_paths = 0, w_exact = 0, w_refine = 0, w_sky = 0, w_shaded = 0;
+    uint32_t w_exact = 0, w_refine = 0;
+    uint32_t l_rays = 0, l_sky = 0;   // this lane's own counts
     // hierarchy scenes: the workgroup stages the top levels of the hierarchy in LDS once (every ray
     // visits them; an LDS read costs a fraction of even an L1 hit and takes no vector-memory slot)
     __shared__ f4 top_nodes[TRI == kTriBvh ? 8 * 2 * kTopNodes : 2];
@@ -385,9 +394,11 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
         if (__ballot(have_job) == 0) break;
         PROF(kProfHandout);
 
-        const bool starting = have_job && !in_path;
-        w_paths += (uint32_t)__builtin_popcountll(__ballot(starting));
-        bool f_ray = false, f_exact = false, f_refine = false, f_sky = false, f_shaded = false;
+        // Statistics: every lane counts its own closest-hit queries and environment lookups (one add
+        // each, where the code runs anyway; summed over the wave at the end of the kernel); the two
+        // rare counters (double-precision work) share one test per trip; paths are not counted at all
+        // (a launch that runs to its end traces rectangle x samples of them, which the host knows).
+        int rare = 0;
         if (have_job) {
             // ---- 2. start the next sample of this lane's pixel --------------------------------
             if (!in_path) {
@@ -422,14 +433,15 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                     BvhCounters second_pass = bc; second_pass.nodes = 0; second_pass.tris = 0;
                     h = hit_finish<TRI, HAS_SPH, false>(S, ray, rr, first, second_pass, nullptr);
                     bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
-                    alive = path_shade(S, p, A.max_bounces, h, er, eg, eb);
-                    f_ray = true;
+                    alive = path_shade(S, p, A.max_bounces, h, er, eg, eb, l_sky);
+                    l_rays += 1u;
+                    rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0);
                 }
             } else {
-                alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h);
-                f_ray = true;
+                l_rays += 1u;
+                alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h, l_sky);
+                rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0);
             }
-            if (f_ray) { f_exact = h.how == 2; f_refine = h.refined; f_sky = h.obj < 0; f_shaded = h.obj >= 0; }
             if (!alive) {
                 ar = fma_(p.tr, er, ar); ag = fma_(p.tg, eg, ag); ab = fma_(p.tb, eb, ab);
                 in_path = false;
@@ -447,11 +459,10 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
             }
         }
         PROF(kProfAccum);
-        w_rays += (uint32_t)__builtin_popcountll(__ballot(f_ray));
-        w_exact += (uint32_t)__builtin_popcountll(__ballot(f_exact));
-        w_refine += (uint32_t)__builtin_popcountll(__ballot(f_refine));
-        w_sky += (uint32_t)__builtin_popcountll(__ballot(f_sky));
-        w_shaded += (uint32_t)__builtin_popcountll(__ballot(f_shaded));
+        if (__ballot(rare != 0) != 0) {
+            w_exact += (uint32_t)__builtin_popcountll(__ballot((rare & 1) != 0));
+            w_refine += (uint32_t)__builtin_popcountll(__ballot((rare & 2) != 0));
+        }
         PROF(kProfStats);
     }
 #ifdef RT_SECTION_TIMERS
@@ -459,17 +470,18 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
         for (int k = 0; k < kProfCount; ++k) atomicAdd(A.prof + k, (unsigned long long)g_prof_acc[threadIdx.x >> 6][k]);
 #endif
     // ---- statistics: one atomic per counter per wave ------------------------------------------
-    unsigned long long nodes = bc.nodes, tris = bc.tris;
-    if (TRI == kTriBvh) {
-        for (int off = 32; off > 0; off >>= 1) { nodes += __shfl_down(nodes, off, 64); tris += __shfl_down(tris, off, 64); }
+    unsigned long long nodes = bc.nodes, tris = bc.tris, w_rays = l_rays, w_sky = l_sky;
+    for (int off = 32; off > 0; off >>= 1) {
+        w_rays += __shfl_down(w_rays, off, 64); w_sky += __shfl_down(w_sky, off, 64);
+        if (TRI == kTriBvh) { nodes += __shfl_down(nodes, off, 64); tris += __shfl_down(tris, off, 64); }
     }
     if (lane_id() == 0) {
         unsigned long long v[kStatCount] = {0};
-        v[kStatRays] = w_rays; v[kStatPaths] = w_paths; v[kStatExact] = w_exact; v[kStatRefine] = w_refine;
-        v[kStatSky] = w_sky; v[kStatShaded] = w_shaded;
-        v[kStatSphTests] = (unsigned long long)w_rays * (uint32_t)(S.n_sph_rows + S.n_big_sph);
+        v[kStatRays] = w_rays; v[kStatExact] = w_exact; v[kStatRefine] = w_refine;
+        v[kStatSky] = w_sky; v[kStatShaded] = w_rays - w_sky;
+        v[kStatSphTests] = w_rays * (uint32_t)(S.n_sph_rows + S.n_big_sph);
         // linear-table tests (dead padding rows are not counted) plus, with a hierarchy, the leaf tests
-        v[kStatTriTests] = (unsigned long long)w_rays * (uint32_t)S.n_tri_rows + (TRI == kTriBvh ? tris : 0ull);
+        v[kStatTriTests] = w_rays * (uint32_t)S.n_tri_rows + (TRI == kTriBvh ? tris : 0ull);
         v[kStatBvhNodes] = nodes;
 #pragma unroll
         for (int i = 0; i < kStatCount; ++i)
@@ -523,7 +535,8 @@ __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S_arg, const
             A.seg_dir[3 * k] = p.dx; A.seg_dir[3 * k + 1] = p.dy; A.seg_dir[3 * k + 2] = p.dz;
         }
         Hit h;
-        bool alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h);
+        uint32_t sky_unused = 0;
+        bool alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h, sky_unused);
         if (n < A.seg_cap) { A.seg_obj[k] = h.obj; A.seg_prim[k] = h.prim; A.seg_how[k] = h.how; A.seg_t[k] = h.t; }
         n++;
         if (!alive) break;
@@ -567,7 +580,8 @@ __global__ __launch_bounds__(256) void k_raytrace(const DevScene S_arg, const Ra
                 const Hit h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, no_residue());
                 rays++;
                 if (h.obj < 0) sky++; else shaded++;
-                if (!path_shade(S, p, A.max_bounces, h, er, eg, eb)) break;
+                uint32_t sky_unused = 0;
+                if (!path_shade(S, p, A.max_bounces, h, er, eg, eb, sky_unused)) break;
             }
         }
         A.rgb[3 * i] = p.tr * er; A.rgb[3 * i + 1] = p.tg * eg; A.rgb[3 * i + 2] = p.tb * eb;

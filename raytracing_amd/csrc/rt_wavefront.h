@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void k_wf_shade(const DevScene S_arg, const Wf
         h.obj = w.obj; h.prim = 0; h.gprim = w.gprim; h.t = 0; h.nx = w.nx; h.ny = w.ny; h.nz = w.nz;
         h.px = w.px; h.py = w.py; h.pz = w.pz; h.how = 0; h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0;
         float er, eg, eb;
-        alive = path_shade(S, p, A.max_bounces, h, er, eg, eb);
+        uint32_t sky_unused = 0;   // (this kernel counts from its own flags)
+        alive = path_shade(S, p, A.max_bounces, h, er, eg, eb, sky_unused);
         f_exact = (w.flags & 1u) != 0; f_refine = (w.flags & 2u) != 0; f_sky = w.obj < 0; f_shaded = w.obj >= 0;
         if (alive) {
             WfPath t = s;
