@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -87,7 +87,21 @@ typedef struct rt_scene_desc {
     int32_t n_bvh_nodes;
     const void *bvh_nodes;         /* [n_bvh_nodes] rt_bvh_node */
     const int32_t *bvh_tri_index;  /* [n_tris] triangle ids in leaf order */
+
+    /* Layout switches for A/B runs, tests and tuning; all zero = the defaults.  Results never depend
+     * on them: every layout returns the same hits.  (No upstream counterpart.) */
+    uint32_t flags;                /* RT_SCENE_* */
+    int32_t linear_max_tris;       /* triangle count up to which the linear tables are kept (0 = 48; at most 4096) */
+    int32_t bvh_leaf_size;         /* leaf target of a hierarchy built by the library (0 = 3) */
+    int32_t build_threads;         /* threads of that build (0 = hardware threads, at most 16) */
 } rt_scene_desc;
+
+enum {
+    RT_SCENE_NO_PAIR_ROWS = 1,     /* every triangle a table row of its own (no parallelogram rows) */
+    RT_SCENE_NO_COMPACT_ROWS = 2,  /* no compact rows for parallelograms in axis-perpendicular planes */
+    RT_SCENE_NO_LINEAR_SPLIT = 4,  /* hierarchy scenes: scene-sized triangles go into the hierarchy too */
+    RT_SCENE_NO_LDS_TOP = 8        /* hierarchy scenes: top levels read from memory instead of LDS */
+};
 
 /* Depth-first ("threaded") BVH node: if the ray misses the box, or after a leaf has been
  * processed, traversal continues at `skip`; otherwise at the next node in memory. */
@@ -106,7 +120,21 @@ typedef struct rt_render_params {
     int32_t sample_count;          /* number of samples (passes) to add per pixel */
     int32_t max_bounces;           /* RenderSettings.MAX_BOUNCES (render_settings.py:19) */
     uint64_t seed;                 /* mixed into the Philox key with (pixel, sample) */
+    uint32_t flags;                /* RT_RENDER_*; 0 = defaults */
+    int32_t wavefront_paths;       /* RT_RENDER_WAVEFRONT: paths in flight per batch (0 = 16 Mi) */
 } rt_render_params;
+
+enum {
+    /* Hierarchy scenes: the wavefront form of the render (generate / extend / shade / resolve kernels
+     * over path queues in memory) instead of the single persistent kernel. */
+    RT_RENDER_WAVEFRONT = 1,
+    /* Accept a float32 hit depth only when its error BOUND is below 9.5e-6 of the depth, as
+     * rt_intersect_batch does; otherwise redo it in double precision.  Without the flag the render
+     * accepts bounds up to 2e-4 relative (or 1e-5 of the scene size absolute): hit identity is exact
+     * either way, and measured depths agree with upstream's to better than 1e-5 in both modes (the
+     * bound is what differs); the strict mode costs about 15 % of render time. */
+    RT_RENDER_STRICT_DEPTH = 2
+};
 
 typedef struct rt_stats {
     uint64_t rays;                 /* closest-hit queries = Scene.intersect calls (scene.py:23) */
@@ -137,6 +165,9 @@ const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: last error of 
  * nodes_out = NULL to learn the count first. */
 int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_bvh_node *nodes_out,
                  int32_t nodes_capacity, int32_t *tri_index_out, int32_t *n_nodes_out);
+/* Threads rt_build_bvh uses (process-wide; 0 = hardware threads, at most 16).  The result does not
+ * depend on it. */
+int rt_build_bvh_threads(int32_t n_threads);
 
 /* Host-side Wavefront OBJ reader with the semantics of Mesh.load_from_obj_file
  * (src/mesh/mesh.py:211-251): one object per "o" record, first index of each a/b/c corner, face
@@ -241,9 +272,10 @@ int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t see
  * device functions the render kernel runs (Camera.get_ray + Renderer.raytrace, camera.py:39-50,
  * renderer.py:21-79), and records every segment.  xys = [n_paths][3] (x, y, sample index).  Outputs
  * are host arrays; per-segment arrays hold max_bounces + 1 entries per path: hit object / primitive
- * (-1 = miss), which code produced the hit (see rt_intersect_batch), depth, ray origin, direction. */
+ * (-1 = miss), which code produced the hit (see rt_intersect_batch), depth, ray origin, direction.
+ * render_flags: RT_RENDER_STRICT_DEPTH or 0, as rt_render takes it. */
 int rt_debug_trace_paths(rt_ctx *ctx, int32_t n_paths, const int32_t *xys, int32_t width, int32_t height,
-                         int32_t max_bounces, uint64_t seed, float *rgb, int32_t *n_seg, int32_t *seg_obj,
+                         int32_t max_bounces, uint64_t seed, uint32_t render_flags, float *rgb, int32_t *n_seg, int32_t *seg_obj,
                          int32_t *seg_prim, int32_t *seg_how, float *seg_t, float *seg_org, float *seg_dir);
 
 #ifdef __cplusplus

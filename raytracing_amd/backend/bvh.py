@@ -31,6 +31,9 @@ def build_flat_bvh(tri_verts: np.ndarray, leaf_size: int = 3) -> tuple[np.ndarra
     if n == 0:
         return np.zeros(0, NODE_DTYPE), np.zeros(0, np.int32)
     lib = load_library()
+    from .packer import layout_switches
+
+    lib.rt_build_bvh_threads(layout_switches()["build_threads"])   # RAYTRACING_AMD_BUILD_THREADS (0 = hardware threads)
     nodes = np.zeros(2 * n, NODE_DTYPE)
     order = np.zeros(n, np.int32)
     n_nodes = C.c_int32(0)

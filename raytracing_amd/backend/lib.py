@@ -24,14 +24,17 @@ RT_ERR_STOPPED = 5
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
            "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms",
-           "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
+           "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_build_bvh_threads", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
 
 class RtRenderParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
                 ("x0", C.c_int32), ("x1", C.c_int32), ("y0", C.c_int32), ("y1", C.c_int32),
                 ("sample_begin", C.c_int32), ("sample_count", C.c_int32), ("max_bounces", C.c_int32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("flags", C.c_uint32), ("wavefront_paths", C.c_int32)]
+
+
+RT_RENDER_WAVEFRONT, RT_RENDER_STRICT_DEPTH = 1, 2
 
 
 class RtPostprocessParams(C.Structure):
@@ -88,12 +91,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
     lib.rt_reset_stats.argtypes = [vp]
     lib.rt_debug_uniforms.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int32, fp]
-    lib.rt_debug_trace_paths.argtypes = [vp, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+    lib.rt_debug_trace_paths.argtypes = [vp, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
                                          fp, ip, ip, ip, ip, fp, fp, fp]
     lib.rt_raytrace_batch.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_uint64,
                                       C.c_uint32, C.c_uint32, fp]
     lib.rt_postprocess.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.POINTER(RtPostprocessParams), vp, vp]
     lib.rt_postprocess_noalloc.argtypes = lib.rt_postprocess.argtypes
+    lib.rt_build_bvh_threads.argtypes = [C.c_int32]
     lib.rt_build_bvh.argtypes = [C.c_int32, dp, C.c_int32, vp, C.c_int32, ip, ip]
     lp = C.POINTER(C.c_int64)
     lib.rt_obj_open.argtypes = [C.c_char_p, C.POINTER(vp), ip, lp, lp]
@@ -181,10 +185,20 @@ class HipBackend:
 
     # -- render ---------------------------------------------------------------------------------
     def render(self, width: int, height: int, sample_begin: int, sample_count: int, max_bounces: int, seed: int,
-               rect=None, accum_ptr: int = 0, stream: int = 0) -> None:
+               rect=None, accum_ptr: int = 0, stream: int = 0, strict_depth: bool = False, wavefront=None,
+               wavefront_paths: int = 0) -> None:
+        """``wavefront`` None takes the switch from the environment (RAYTRACING_AMD_WAVEFRONT /
+        RAYTRACING_AMD_WF_PATHS: A/B runs and tests); the library itself reads no environment variable."""
         x0, x1, y0, y1 = rect if rect is not None else (0, width, 0, height)
+        if wavefront is None:
+            wavefront = bool(os.environ.get("RAYTRACING_AMD_WAVEFRONT"))
+            try:
+                wavefront_paths = wavefront_paths or int(os.environ.get("RAYTRACING_AMD_WF_PATHS", "0") or 0)
+            except ValueError:
+                wavefront_paths = 0
+        flags = (RT_RENDER_WAVEFRONT if wavefront else 0) | (RT_RENDER_STRICT_DEPTH if strict_depth else 0)
         p = RtRenderParams(C.sizeof(RtRenderParams), width, height, x0, x1, y0, y1, sample_begin, sample_count,
-                           max_bounces, seed & 0xFFFFFFFFFFFFFFFF)
+                           max_bounces, seed & 0xFFFFFFFFFFFFFFFF, flags, max(0, int(wavefront_paths)))
         self._check(self.lib.rt_render(self.handle, C.byref(p), C.c_void_p(accum_ptr or None), C.c_void_p(stream or None)))
 
     def postprocess(self, width: int, height: int, dst_ptr: int, src_ptr: int = 0, scale: float = 1.0, flip_y: bool = False,
@@ -243,7 +257,7 @@ class HipBackend:
                                                out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
-    def trace_paths(self, xys, width: int, height: int, max_bounces: int, seed: int) -> dict:
+    def trace_paths(self, xys, width: int, height: int, max_bounces: int, seed: int, strict_depth: bool = False) -> dict:
         """Whole paths with per-segment records (diagnostics / parity tests)."""
         xys = np.ascontiguousarray(xys, dtype=np.int32).reshape(-1, 3)
         n, cap = xys.shape[0], max_bounces + 1
@@ -253,6 +267,7 @@ class HipBackend:
         ip, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
         self._check(self.lib.rt_debug_trace_paths(
             self.handle, n, xys.ctypes.data_as(ip), width, height, max_bounces, seed & 0xFFFFFFFFFFFFFFFF,
+            RT_RENDER_STRICT_DEPTH if strict_depth else 0,
             out["rgb"].ctypes.data_as(fp), out["n_seg"].ctypes.data_as(ip), out["obj"].ctypes.data_as(ip),
             out["prim"].ctypes.data_as(ip), out["how"].ctypes.data_as(ip), out["t"].ctypes.data_as(fp),
             out["org"].ctypes.data_as(fp), out["dir"].ctypes.data_as(fp)))

@@ -18,6 +18,7 @@ its float32 working set from these tables.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Any, Optional
 
@@ -59,7 +60,39 @@ class RtSceneDesc(C.Structure):
         ("n_bvh_nodes", C.c_int32),
         ("bvh_nodes", C.c_void_p),
         ("bvh_tri_index", C.POINTER(C.c_int32)),
+        ("flags", C.c_uint32),
+        ("linear_max_tris", C.c_int32),
+        ("bvh_leaf_size", C.c_int32),
+        ("build_threads", C.c_int32),
     ]
+
+
+# rt_scene_desc.flags
+RT_SCENE_NO_PAIR_ROWS, RT_SCENE_NO_COMPACT_ROWS, RT_SCENE_NO_LINEAR_SPLIT, RT_SCENE_NO_LDS_TOP = 1, 2, 4, 8
+
+
+def layout_switches() -> dict:
+    """The layout switches of ``rt_scene_desc`` as the environment sets them (all optional, for A/B
+    runs, tests and tuning; the library itself reads no environment variable)."""
+    env = os.environ
+    flags = 0
+    if env.get("RAYTRACING_AMD_NO_QUADS"):
+        flags |= RT_SCENE_NO_PAIR_ROWS
+    if env.get("RAYTRACING_AMD_NO_SLABS"):
+        flags |= RT_SCENE_NO_COMPACT_ROWS
+    if env.get("RAYTRACING_AMD_NO_LINEAR_SPLIT"):
+        flags |= RT_SCENE_NO_LINEAR_SPLIT
+    if env.get("RAYTRACING_AMD_NO_LDS_TOP"):
+        flags |= RT_SCENE_NO_LDS_TOP
+
+    def num(name):
+        try:
+            return max(0, int(env.get(name, "0") or 0))
+        except ValueError:
+            return 0
+
+    return dict(flags=flags, linear_max_tris=num("RAYTRACING_AMD_LINEAR_MAX_TRIS"), bvh_leaf_size=num("RAYTRACING_AMD_BVH_LEAF"),
+                build_threads=num("RAYTRACING_AMD_BUILD_THREADS"))
 
 
 def _vec(v) -> tuple[float, float, float]:
@@ -155,6 +188,9 @@ class PackedScene:
             d.n_bvh_nodes = -1 if self.library_bvh else 0
             d.bvh_nodes = None
             d.bvh_tri_index = C.cast(None, C.POINTER(C.c_int32))
+        sw = layout_switches()
+        d.flags, d.linear_max_tris = sw["flags"], sw["linear_max_tris"]
+        d.bvh_leaf_size, d.build_threads = sw["bvh_leaf_size"], sw["build_threads"]
         return d
 
     def with_subdivided_mesh(self, mesh: int, levels: int) -> "PackedScene":

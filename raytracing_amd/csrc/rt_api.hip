@@ -31,6 +31,7 @@ using namespace rt;
 namespace {
 
 thread_local std::string g_create_error;
+std::atomic<int> g_build_threads{0};   // rt_build_bvh_threads
 
 struct DevBuf {
     void *p = nullptr;
@@ -101,6 +102,7 @@ struct rt_ctx {
     double *post_scratch = nullptr;   // rt_postprocess_noalloc: this GPU's copy of the static scratch array
     DevBuf wf_rays[2], wf_paths, wf_hits, wf_radiance, wf_counters, wf_partials;   // wavefront form (hierarchy scenes)
     DevBuf ray_dir, ray_res; int ray_w = 0, ray_h = 0;   // camera-ray table of the current scene at ray_w x ray_h
+    DevBuf isect_in, isect_out;          // rt_intersect_batch staging, grow-only (one call in flight per context)
     std::vector<EventPair> timed;        // recorded around render launches, not yet read
     std::vector<EventPair> spare_events; // read and ready for reuse (events are created once, not per launch)
     double kernel_ms = 0; uint64_t launches = 0;
@@ -228,11 +230,17 @@ int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_
                  int32_t *tri_index_out, int32_t *n_nodes_out) {
     if (n_tris <= 0 || n_tris >= (1 << 27) || !tri_verts || !tri_index_out || !n_nodes_out || nodes_capacity < 0) return RT_ERR_INVALID_ARG;
     bvh::Builder b;
-    b.run(n_tris, tri_verts, leaf_size > 0 ? leaf_size : 3);
+    b.run(n_tris, tri_verts, leaf_size > 0 ? leaf_size : 3, nullptr, g_build_threads.load());
     *n_nodes_out = (int32_t)b.nodes.size();
     std::memcpy(tri_index_out, b.order.data(), sizeof(int32_t) * (size_t)n_tris);
     if ((int64_t)b.nodes.size() > nodes_capacity || !nodes_out) return nodes_out ? RT_ERR_INVALID_ARG : RT_OK;
     std::memcpy(nodes_out, b.nodes.data(), sizeof(rt_bvh_node) * b.nodes.size());
+    return RT_OK;
+}
+
+int rt_build_bvh_threads(int32_t n_threads) {
+    if (n_threads < 0) return RT_ERR_INVALID_ARG;
+    g_build_threads.store(n_threads);
     return RT_OK;
 }
 
@@ -263,8 +271,9 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     // the caller asks for it (n_bvh_nodes != 0).
     // Measured on room + k triangles of a mesh (G rays/s, linear / hierarchy): 38 triangles 24.7 / 23.5,
     // 54: 18.8 / 21.8, 86: 12.5 / 19.4, 150: 7.6 / 16.9, 310: 3.7 / 13.8 - so the linear tables are left at 48.
-    int linear_max_tris = 48;
-    if (const char *e = std::getenv("RAYTRACING_AMD_LINEAR_MAX_TRIS")) linear_max_tris = std::min(std::max(0, std::atoi(e)), 4096);
+    if (d->linear_max_tris < 0 || d->bvh_leaf_size < 0 || d->build_threads < 0)
+        return fail(c, RT_ERR_INVALID_ARG, "negative tuning value in scene description");
+    const int linear_max_tris = d->linear_max_tris > 0 ? std::min(d->linear_max_tris, 4096) : 48;
     const bool use_bvh = d->n_tris > 0 && (d->n_bvh_nodes != 0 || n_gprim > 4096 || d->n_tris > linear_max_tris);
     if (!use_bvh && n_gprim > 4096)
         return fail(c, RT_ERR_UNSUPPORTED, "%lld primitives without triangles: the linear sphere walk takes at most 4096", n_gprim);
@@ -299,7 +308,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             }
             const double scene_area = (hi[0] - lo[0]) * (hi[1] - lo[1]) + (hi[1] - lo[1]) * (hi[2] - lo[2]) + (hi[2] - lo[2]) * (hi[0] - lo[0]);
             std::vector<int32_t> large;
-            if (std::getenv("RAYTRACING_AMD_NO_LINEAR_SPLIT") == nullptr)
+            if (!(d->flags & RT_SCENE_NO_LINEAR_SPLIT))
                 for (int t = 0; t < d->n_tris; ++t) if (area[t] >= 0.01 * scene_area) large.push_back(t);
             if (large.size() > 128) {
                 std::sort(large.begin(), large.end(), [&](int32_t a, int32_t b) { return area[a] > area[b]; });
@@ -312,13 +321,18 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             for (int t = 0; t < d->n_tris; ++t) if (!linear_tri[t]) rest.push_back(t);
             if (rest.empty()) { rest.push_back(large.back()); linear_tri[large.back()] = 0; }   // keep the hierarchy non-empty
             bvh::Builder b;
-            const char *leaf_env = std::getenv("RAYTRACING_AMD_BVH_LEAF");   // tuning switch; default 3 (measured 1 ... 8 on 310 ... 1.18 M triangles)
-            b.run(d->n_tris, d->tri_verts, leaf_env ? std::atoi(leaf_env) : 3, &rest);
+            // leaf target: default 3 (measured 1 ... 8 on 310 ... 1.18 M triangles)
+            b.run(d->n_tris, d->tri_verts, d->bvh_leaf_size > 0 ? d->bvh_leaf_size : 3, &rest, d->build_threads);
             bvh_nodes.swap(b.nodes); bvh_order.swap(b.order);
         }
     }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
+    // From here on the tables of the previous scene are being replaced (uploads may free and
+    // reallocate them): until everything has arrived the context has NO scene, so that a failed
+    // upload leaves later calls with RT_ERR_NO_SCENE instead of pointers into freed memory.
+    c->has_scene = false;
+    c->ray_w = c->ray_h = 0;
 
     const V3 cam = {d->cam_pos[0], d->cam_pos[1], d->cam_pos[2]};
     double scene_radius = norm(cam);
@@ -417,7 +431,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     std::vector<PairInfo> pair_info;
     int n_live_tris = 0;
     {
-        const bool merge_pairs = std::getenv("RAYTRACING_AMD_NO_QUADS") == nullptr;   // switch for A/B runs and tests
+        const bool merge_pairs = !(d->flags & RT_SCENE_NO_PAIR_ROWS);   // switch for A/B runs and tests
         auto in_linear = [&](int t) { return !use_bvh || (!linear_tri.empty() && linear_tri[t]); };
         std::vector<char> taken(d->n_tris, 0);
         auto vtx = [&](int t, int k) { const double *v = d->tri_verts + 9 * (size_t)t + 3 * k; return V3{v[0], v[1], v[2]}; };
@@ -464,7 +478,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
                 // the compact form reads e1/e2 without their component along the axis: it must be exactly zero
                 if (axis >= 0 && ((axis == 0 && (r.e1x != 0 || r.e2x != 0)) || (axis == 1 && (r.e1y != 0 || r.e2y != 0)) ||
                                   (axis == 2 && (r.e1z != 0 || r.e2z != 0)))) axis = -1;
-                if (std::getenv("RAYTRACING_AMD_NO_SLABS")) axis = -1;   // switch for A/B runs and tests
+                if (d->flags & RT_SCENE_NO_COMPACT_ROWS) axis = -1;   // switch for A/B runs and tests
                 pair_info.push_back({t, axis, c0, nl});
                 break;
             }
@@ -601,7 +615,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.materials = c->materials.as<MatRow>();
     S.leaf_rows = c->leaf_rows.as<TriRow>();
     S.bvh_nodes = use_bvh ? c->bvh.as<BvhNode>() : nullptr; S.n_bvh_nodes = use_bvh ? (int32_t)bvh_nodes.size() : 0;
-    S.n_top_nodes = std::getenv("RAYTRACING_AMD_NO_LDS_TOP") ? 0 : n_top_nodes;   // switch for A/B runs
+    S.n_top_nodes = (d->flags & RT_SCENE_NO_LDS_TOP) ? 0 : n_top_nodes;   // switch for A/B runs
     ColdScene cold{};
     cold.tri64 = c->tri64.as<double>(); cold.sph64 = c->sph64.as<double>(); cold.aabb64 = c->aabb64.as<double>();
     cold.mesh_tri_begin = c->mesh_tri_begin.as<int32_t>(); cold.obj_kind = c->obj_kind.as<int32_t>(); cold.obj_index = c->obj_index.as<int32_t>();
@@ -727,21 +741,27 @@ int rt_intersect_batch(rt_ctx *c, int64_t n, const double *org, const double *di
     if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "rt_intersect_batch: no scene set");
     if (n == 0) return RT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    DevBuf b_org, b_dir, b_origin, b_obj, b_prim, b_gprim, b_how, b_t, b_n, b_p;
-    const size_t n3 = 3 * (size_t)n * sizeof(double);
-    HIP_TRY(c, b_org.ensure(n3)); HIP_TRY(c, b_dir.ensure(n3));
-    HIP_TRY(c, hipMemcpy(b_org.p, org, n3, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(b_dir.p, dir, n3, hipMemcpyHostToDevice));
-    if (origin_prim) {
-        HIP_TRY(c, b_origin.ensure(n * sizeof(int32_t)));
-        HIP_TRY(c, hipMemcpy(b_origin.p, origin_prim, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    // Staging lives in two context-owned buffers that only ever grow (a closest-hit query for one ray -
+    // Scene.intersect(ray) - used to pay ten allocations and frees): inputs org | dir | origin, outputs
+    // t | normal | pos | obj | prim | gprim | how, each array aligned to 16 bytes.
+    const size_t N = (size_t)n, n3 = 3 * N * sizeof(double);
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t in_org = 0, in_dir = al(n3), in_origin = in_dir + al(n3), in_bytes = in_origin + al(N * 4);
+    const size_t o_t = 0, o_n = al(N * 8), o_p = o_n + al(n3), o_obj = o_p + al(n3), o_prim = o_obj + al(N * 4),
+                 o_gprim = o_prim + al(N * 4), o_how = o_gprim + al(N * 4), out_bytes = o_how + al(N * 4);
+    if (in_bytes > c->isect_in.bytes || out_bytes > c->isect_out.bytes) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        HIP_TRY(c, c->isect_in.ensure(in_bytes + in_bytes / 2)); HIP_TRY(c, c->isect_out.ensure(out_bytes + out_bytes / 2));
     }
-    HIP_TRY(c, b_obj.ensure(n * 4)); HIP_TRY(c, b_prim.ensure(n * 4)); HIP_TRY(c, b_gprim.ensure(n * 4)); HIP_TRY(c, b_how.ensure(n * 4));
-    HIP_TRY(c, b_t.ensure(n * 8)); HIP_TRY(c, b_n.ensure(n3)); HIP_TRY(c, b_p.ensure(n3));
+    char *bi = c->isect_in.as<char>(), *bo = c->isect_out.as<char>();
+    HIP_TRY(c, hipMemcpy(bi + in_org, org, n3, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(bi + in_dir, dir, n3, hipMemcpyHostToDevice));
+    if (origin_prim) HIP_TRY(c, hipMemcpy(bi + in_origin, origin_prim, N * 4, hipMemcpyHostToDevice));
     IsectArgs A{};
-    A.n = n; A.org = b_org.as<double>(); A.dir = b_dir.as<double>(); A.origin = origin_prim ? b_origin.as<int32_t>() : nullptr;
-    A.obj = b_obj.as<int32_t>(); A.prim = b_prim.as<int32_t>(); A.gprim = b_gprim.as<int32_t>(); A.how = b_how.as<int32_t>();
-    A.t = b_t.as<double>(); A.normal = b_n.as<double>(); A.pos = b_p.as<double>(); A.stats = c->stats.as<unsigned long long>();
+    A.n = n; A.org = (const double *)(bi + in_org); A.dir = (const double *)(bi + in_dir);
+    A.origin = origin_prim ? (const int32_t *)(bi + in_origin) : nullptr;
+    A.obj = (int32_t *)(bo + o_obj); A.prim = (int32_t *)(bo + o_prim); A.gprim = (int32_t *)(bo + o_gprim); A.how = (int32_t *)(bo + o_how);
+    A.t = (double *)(bo + o_t); A.normal = (double *)(bo + o_n); A.pos = (double *)(bo + o_p); A.stats = c->stats.as<unsigned long long>();
     const unsigned blocks = (unsigned)((n + 255) / 256);
     const DevScene S = c->S;
     dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
@@ -749,13 +769,13 @@ int rt_intersect_batch(rt_ctx *c, int64_t n, const double *org, const double *di
     });
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(obj, b_obj.p, n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(prim, b_prim.p, n * 4, hipMemcpyDeviceToHost));
-    if (gprim) HIP_TRY(c, hipMemcpy(gprim, b_gprim.p, n * 4, hipMemcpyDeviceToHost));
-    if (how) HIP_TRY(c, hipMemcpy(how, b_how.p, n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(t, b_t.p, n * 8, hipMemcpyDeviceToHost));
-    if (normal) HIP_TRY(c, hipMemcpy(normal, b_n.p, n3, hipMemcpyDeviceToHost));
-    if (pos) HIP_TRY(c, hipMemcpy(pos, b_p.p, n3, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(obj, bo + o_obj, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(prim, bo + o_prim, N * 4, hipMemcpyDeviceToHost));
+    if (gprim) HIP_TRY(c, hipMemcpy(gprim, bo + o_gprim, N * 4, hipMemcpyDeviceToHost));
+    if (how) HIP_TRY(c, hipMemcpy(how, bo + o_how, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(t, bo + o_t, N * 8, hipMemcpyDeviceToHost));
+    if (normal) HIP_TRY(c, hipMemcpy(normal, bo + o_n, n3, hipMemcpyDeviceToHost));
+    if (pos) HIP_TRY(c, hipMemcpy(pos, bo + o_p, n3, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -803,8 +823,7 @@ namespace {
 int render_wavefront(rt_ctx *c, const rt_render_params *p, float *accum, hipStream_t stream) {
     const long long rect_px = (long long)(p->x1 - p->x0) * (p->y1 - p->y0);
     // paths in flight per batch: enough that even the last, sparsely populated segments fill the GPU
-    long long target = 16ll << 20;
-    if (const char *e = std::getenv("RAYTRACING_AMD_WF_PATHS")) target = std::max(1ll << 16, std::atoll(e));
+    const long long target = p->wavefront_paths > 0 ? std::max<long long>(1ll << 16, p->wavefront_paths) : 16ll << 20;
     const int batch_cap = (int)std::max<long long>(1, std::min<long long>(p->sample_count, target / rect_px));
     const size_t cap_paths = (size_t)rect_px * batch_cap;
     if (cap_paths >= (1ull << 31)) return fail(c, RT_ERR_INVALID_ARG, "rt_render: rectangle too large for one wavefront batch");
@@ -884,6 +903,10 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
         return fail(c, RT_ERR_INVALID_ARG, "rt_render: rectangle [%d,%d)x[%d,%d) outside %dx%d", p->x0, p->x1, p->y0, p->y1, p->width, p->height);
     if (p->sample_count < 0 || p->sample_begin < 0 || p->max_bounces < 0 || p->max_bounces > 62)
         return fail(c, RT_ERR_INVALID_ARG, "rt_render: bad sample range or max_bounces");
+    if ((p->flags & ~(uint32_t)(RT_RENDER_WAVEFRONT | RT_RENDER_STRICT_DEPTH)) != 0 || p->wavefront_paths < 0)
+        return fail(c, RT_ERR_INVALID_ARG, "rt_render: unknown flag bits 0x%x or negative wavefront_paths", p->flags);
+    if ((p->flags & RT_RENDER_WAVEFRONT) && (p->flags & RT_RENDER_STRICT_DEPTH))
+        return fail(c, RT_ERR_UNSUPPORTED, "rt_render: the wavefront form has no strict-depth variant");
     float *accum = accum_dev;
     if (!accum) {
         if (c->acc_w != p->width || c->acc_h != p->height)
@@ -897,7 +920,7 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     // The wavefront form exists for hierarchy scenes and is selectable, but the single kernel below
     // is faster on every configuration measured (room + 1.18 M triangles, 1080p: 4.1 against 3.3
     // G rays/s with 64 M paths in flight, 1.4 with 4 M), so it stays the default.
-    if (c->tri_mode == kTriBvh && std::getenv("RAYTRACING_AMD_WAVEFRONT") != nullptr)
+    if (c->tri_mode == kTriBvh && (p->flags & RT_RENDER_WAVEFRONT))
         return render_wavefront(c, p, accum, stream);
 
     // Job granularity: enough (pixel, chunk) jobs that every resident lane runs many of them, so the
@@ -937,8 +960,10 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     if (!have_ev) { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
     HIP_TRY(c, hipEventRecord(ev.a, stream));
     const DevScene S = c->S;
+    const bool strict = (p->flags & RT_RENDER_STRICT_DEPTH) != 0;
     dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
-        hipLaunchKernelGGL((k_render<decltype(T)::value, decltype(P)::value>), dim3(blocks), dim3(256), 0, stream, S, A);
+        if (strict) hipLaunchKernelGGL((k_render<decltype(T)::value, decltype(P)::value, true>), dim3(blocks), dim3(256), 0, stream, S, A);
+        else hipLaunchKernelGGL((k_render<decltype(T)::value, decltype(P)::value, false>), dim3(blocks), dim3(256), 0, stream, S, A);
     });
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(ev.b, stream));
@@ -1038,7 +1063,7 @@ extern "C" int rt_debug_uniforms(rt_ctx *c, uint32_t pixel, uint32_t sample, uin
 
 // Whole paths, one per thread, with every segment recorded (parity tests; not a fast path).
 extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *xys, int32_t width, int32_t height,
-                                    int32_t max_bounces, uint64_t seed, float *rgb, int32_t *n_seg, int32_t *seg_obj,
+                                    int32_t max_bounces, uint64_t seed, uint32_t render_flags, float *rgb, int32_t *n_seg, int32_t *seg_obj,
                                     int32_t *seg_prim, int32_t *seg_how, float *seg_t, float *seg_org, float *seg_dir) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (n_paths <= 0 || !xys || !rgb || !n_seg || !seg_obj || !seg_prim || !seg_how || !seg_t || !seg_org || !seg_dir ||
@@ -1065,8 +1090,12 @@ extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *x
     A.seg_org = b_org.as<float>(); A.seg_dir = b_dir.as<float>();
     const DevScene S = c->S;
     dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
-        hipLaunchKernelGGL((k_trace_paths<decltype(T)::value, decltype(P)::value>),
-                           dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, 0, S, A);
+        if (render_flags & RT_RENDER_STRICT_DEPTH)
+            hipLaunchKernelGGL((k_trace_paths<decltype(T)::value, decltype(P)::value, true>),
+                               dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, 0, S, A);
+        else
+            hipLaunchKernelGGL((k_trace_paths<decltype(T)::value, decltype(P)::value, false>),
+                               dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, 0, S, A);
     });
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipDeviceSynchronize());

@@ -51,7 +51,7 @@ struct Builder {
     std::vector<rt_bvh_node> nodes;
 
     // `subset` (optional): the triangle ids to build over; the others appear in no leaf.
-    void run(int64_t n, const double *verts, int leaf_size, const std::vector<int32_t> *subset = nullptr) {
+    void run(int64_t n, const double *verts, int leaf_size, const std::vector<int32_t> *subset = nullptr, int want_threads = 0) {
         leaf_target = std::max(1, std::min(leaf_size, kMaxLeaf));
         tri_box.resize(n); centroid.resize(3 * (size_t)n);
         if (subset) order = *subset;
@@ -70,7 +70,7 @@ struct Builder {
         nodes.clear();
         nodes.reserve((size_t)(2 * n / std::max(1, leaf_target)) + 16);
         int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-        if (const char *e = std::getenv("RAYTRACING_AMD_BUILD_THREADS")) threads = std::min(std::max(1, std::atoi(e)), kMaxThreads);
+        if (want_threads > 0) threads = std::min(want_threads, kMaxThreads);
         if (order.size() < 65536) threads = 1;
         if (order.empty()) {}
         else if (threads > 1) build_parallel(threads);

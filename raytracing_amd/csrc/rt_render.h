@@ -263,12 +263,12 @@ RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float
 }
 
 // One segment: closest hit, then environment or one bounce.
-template <int TRI, bool HAS_SPH>
+template <int TRI, bool HAS_SPH, bool STRICT = false>
 RT_DEV bool path_step(SceneRef S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h,
                       uint32_t &sky_count) {
     Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag);
     PROF(kProfRaySetup);
-    h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, path_residue(S, ray_res, p));
+    h = closest_hit<TRI, HAS_SPH, STRICT>(S, ray, nullptr, path_residue(S, ray_res, p));
     const bool alive = path_shade(S, p, max_bounces, h, er, eg, eb, sky_count);
     PROF(kProfBounce);
     return alive;
@@ -300,7 +300,9 @@ RT_DEV KernargRenderArgs kernarg_render_args() {
 constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at a time
 constexpr int kWalkSlice = 8;   // boxes a lane visits per trip of the render loop (hierarchy scenes)
 
-template <int TRI, bool HAS_SPH>
+// STRICT: a float32 hit depth is accepted only under the closest-hit entry's error bound (9.5e-6
+// relative) instead of the render's looser one (see kRelAcceptRender); hit identity is the same.
+template <int TRI, bool HAS_SPH, bool STRICT>
 __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const RenderArgs A) {
     SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     // wave-uniform job window
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                 if (walk_node < 0) {
                     walking = false;
                     BvhCounters second_pass = bc; second_pass.nodes = 0; second_pass.tris = 0;
-                    h = hit_finish<TRI, HAS_SPH, false>(S, ray, rr, first, second_pass, nullptr);
+                    h = hit_finish<TRI, HAS_SPH, STRICT>(S, ray, rr, first, second_pass, nullptr);
                     bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
                     alive = path_shade(S, p, A.max_bounces, h, er, eg, eb, l_sky);
                     l_rays += 1u;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                 }
             } else {
                 l_rays += 1u;
-                alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h, l_sky);
+                alive = path_step<TRI, HAS_SPH, STRICT>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h, l_sky);
                 rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0);
             }
             if (!alive) {
@@ -518,7 +520,7 @@ struct TraceArgs {
     float *seg_org, *seg_dir;    // [n_paths][seg_cap][3]
 };
 
-template <int TRI, bool HAS_SPH>
+template <int TRI, bool HAS_SPH, bool STRICT>
 __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S_arg, const TraceArgs A) {
     SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S_arg, const
         }
         Hit h;
         uint32_t sky_unused = 0;
-        bool alive = path_step<TRI, HAS_SPH>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h, sky_unused);
+        bool alive = path_step<TRI, HAS_SPH, STRICT>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h, sky_unused);
         if (n < A.seg_cap) { A.seg_obj[k] = h.obj; A.seg_prim[k] = h.prim; A.seg_how[k] = h.how; A.seg_t[k] = h.t; }
         n++;
         if (!alive) break;

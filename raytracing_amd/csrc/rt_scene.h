@@ -7,6 +7,7 @@
 //   * the float64 tables exactly as the host objects hold them, read only by the exact code that
 //     resolves whatever the float32 filter could not decide.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace rt {
@@ -91,37 +92,45 @@ struct ColdScene {
 };
 
 struct DevScene {
-    // float32 filter tables
-    const TriRow *tri_rows;   int32_t n_tri_rows;     // live triangles the table stands for (a parallelogram row counts two);
-                                                      // rows are padded with dead ones:
-    int32_t n_tri_rows_padded;                        //   even, and 2 more rows exist past it
-    const TriRow *quad_rows;  int32_t n_quad_rows_padded;   // parallelogram rows (two triangles each), padded likewise
+    // Members are ordered by where the render loop reads them, so that the members one stage needs
+    // sit in one run of 16 dwords and reach the scalar registers with one load (see hot_scene_*).
+    // ---- first pass (16 dwords): the float32 filter tables and their sizes
+    const SphRow *sph_rows;                           // small spheres only
     // First passes that take one candidate per parallelogram walk quad_rows[0, n_quad_general) and, for
     // the rows behind those - the ones in axis-perpendicular planes - the compact table instead:
-    const SlabRow *slab_rows; int32_t n_quad_general;
-    uint32_t slab_counts;     // rows per axis: x | y << 10 | z << 20, stored in that order, one dead row at the end
-    const SphRow *sph_rows;   int32_t n_sph_rows;     // small spheres only
-    const int32_t *big_sph;   int32_t n_big_sph;      // sphere indices evaluated in float64
-    const TriRow *tri_by_id;                          // [n_tris] same rows, indexed by triangle id
+    const SlabRow *slab_rows;
+    const TriRow *quad_rows;                          // parallelogram rows (two triangles each), padded like tri_rows
+    const TriRow *tri_rows;                           // live triangles that head no parallelogram row, padded with dead rows:
+    int32_t n_sph_rows, n_big_sph;                    // n_big_sph: spheres evaluated in float64 (indices in big_sph)
+    uint32_t slab_counts;     // rows per axis: x | y << 10 | z << 20, stored in that order, each axis an even count, one dead row at the end
+    int32_t n_quad_general;
+    int32_t n_quad_rows_padded;
+    int32_t n_tri_rows_padded;                        //   even, and 2 more rows exist past it
+    uint32_t key_mask;        // low bits of a hit key that hold the primitive id
+    float scene_radius;       // bound on the distance from the world origin of every vertex, small-sphere point and the camera
+    // ---- winner, hit record, shading (16 dwords)
     const TriAux *tri_aux;                            // [n_tris]
+    const TriRow *tri_by_id;                          // [n_tris] same rows, indexed by triangle id
     const SphRow *sph_by_id;                          // [n_spheres]
     const int32_t *sph_obj;                           // [n_spheres]
     const MatRow *materials;                          // [n_objects]
     const ColdScene *cold;                            // device memory
+    int32_t n_spheres;
+    int32_t n_prims;          // n_spheres + number of triangles: candidate ids are clamped below it before they index a table
+    int32_t n_tri_rows;       // live triangles the linear tables stand for (a parallelogram row counts two)
+    int32_t dof_on;
+    // ---- camera, environment
+    // camera: float32 position and its double-precision residue (pinhole rays come from k_raygen's table)
+    float cam_pos[3], cam_res[3];
+    const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale; int32_t pad0;   // environment: RGBA8 texels, row-major
+    // ---- the few huge spheres, the hierarchy
+    const int32_t *big_sph;                           // sphere indices evaluated in float64
     const TriRow *leaf_rows;                          // hierarchy: triangle rows in leaf order
     const BvhNode *bvh_nodes; int32_t n_bvh_nodes;    // threaded hierarchy over leaf_rows: 8 copies of n_bvh_nodes nodes, one per
                                                       // ray-direction octant, each with its top levels first; 0 = none
     int32_t n_top_nodes;                              // per copy, the first n_top_nodes nodes are the top levels (staged in LDS)
-    int32_t n_spheres;
-    int32_t n_prims;          // n_spheres + number of triangles: candidate ids are clamped below it before they index a table
-    float scene_radius;       // bound on the distance from the world origin of every vertex, small-sphere point and the camera
-    uint32_t key_mask;        // low bits of a hit key that hold the primitive id
-    // camera: float32 position and its double-precision residue (pinhole rays come from k_raygen's table)
-    float cam_pos[3], cam_res[3];
-    int32_t dof_on;
-    // environment: RGBA8 texels, row-major
-    const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale;
 };
+static_assert(offsetof(DevScene, tri_aux) == 64 && offsetof(DevScene, cam_pos) == 128, "DevScene: the two hot runs are 16 dwords each");
 
 // Device code reads the scene where the launch put it: the kernel-argument block, which is constant
 // memory.  A member read through this reference is a scalar load at the point of use, not a scalar

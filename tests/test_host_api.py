@@ -134,8 +134,8 @@ def test_library_exports_every_declared_symbol():
     handle = rtlib.load_library()
     for name in declared:
         assert hasattr(handle, name), name
-    assert handle.rt_abi_version() == 1
-    assert C.sizeof(rtlib.RtRenderParams) == 48
+    assert handle.rt_abi_version() == 2
+    assert C.sizeof(rtlib.RtRenderParams) == 56
 
 
 def test_no_cpu_fallback():
