@@ -6,17 +6,26 @@
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one full render of the workload.  With N > 1 the 256 samples of every pixel are split
-across the ranks (weak scaling is NOT what this does: total work is fixed, so "scaling": "strong"),
-each rank renders its share into its own device buffer, and one RCCL all-reduce merges the
-buffers; the timed region contains the render kernels and the all-reduce.  Scene tables and the
-sky image are resident in HBM before the timed region starts.
+across the ranks (total work is fixed, so "scaling": "strong"), each rank renders its share into its
+own device buffer, and one RCCL all-reduce merges the buffers - issued by the library itself
+(rt_merge) when its communicator can be set up, else through torch.distributed; the line says which.
+The timed region contains the render kernels and the all-reduce.  Scene tables and the sky image
+are resident in HBM before the timed region starts.
 
 Prints ONE JSON line on rank 0, with
-  roofline     - float32 VALU roofline of the render kernel: algorithmic FLOPs (tests executed x
-                 fixed per-test constants, listed below) / kernel time from HIP events recorded
-                 on the launch stream, against the 157.3 TFLOP/s vector peak
-  cpu_baseline - the double-precision CPU restatement (oracle/rt_oracle.c) of the same path,
-                 timed on this host on a bounded sample of the same workload.
+  roofline      - float32 VALU roofline of the render kernel: algorithmic FLOPs (tests executed x
+                  fixed per-test constants, listed below) / kernel time from HIP events recorded on
+                  the launch stream, against the 157.3 TFLOP/s vector peak.  `frac` is that
+                  ALGORITHMIC figure; `executed_frac` is what the vector units actually executed
+                  (PMC pass committed under profiles/), and the depth acceptance the kernel was
+                  timed with is stated next to them;
+  value_strict  - the same workload with RT_RENDER_STRICT_DEPTH (depth error bound 9.5e-6), timed
+                  right after the headline steps (N = 1 only);
+  step_ms_*, kernel_ms_* - the spread of the K timed steps, so that one slow step cannot hide in a mean;
+  other_configs - BASELINE configs[1], [3] and one GPU's share of [4], each run ONCE outside the timed
+                  region of the headline, with a roofline object of its own (N = 1 only);
+  cpu_baseline  - the double-precision CPU restatement (oracle/rt_oracle.c) of the same path,
+                  timed on this host on a bounded sample of the same workload.
 """
 from __future__ import annotations
 
@@ -24,6 +33,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,34 +44,66 @@ sys.path.insert(0, REPO)
 
 WIDTH, HEIGHT, SPP, BOUNCES, SEED = 1920, 1080, 256, 8, 2025
 PEAK_FP32_VALU_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
 # Algorithmic FLOPs per unit of work (FMA = 2, every other arithmetic op or compare = 1, loop
 # invariants hoisted): ray-sphere test 20 (sphere.py:15-20), + 12 when the discriminant is not
-# negative, ray-triangle test 46 (mesh.py:122-136 with ab, ac, N precomputed), one bounce 120
-# (renderer.py:39-79 + hit point / normal), one camera ray 40 (camera.py:40-49), one sky lookup 20.
-F_SPHERE, F_SPHERE_HIT, F_TRI, F_SHADE, F_RAYGEN, F_SKY = 20, 12, 46, 120, 40, 20
+# negative, ray-triangle test 46 (mesh.py:122-136 with ab, ac, N precomputed), ray-box test 24
+# (mesh.py:76-92), one bounce 120 (renderer.py:39-79 + hit point / normal), one camera ray 40
+# (camera.py:40-49), one sky lookup 20.
+F_SPHERE, F_SPHERE_HIT, F_TRI, F_AABB, F_SHADE, F_RAYGEN, F_SKY = 20, 12, 46, 24, 120, 40, 20
+# depth acceptance of the render kernel (rt_filter.h: kRelAcceptRender / kAbsAcceptRender, kRelAcceptStrict)
+DEPTH_ACCEPT = {"default": {"rel": 2e-4, "abs_of_scene_size": 1e-5}, "strict": {"rel": 9.5e-6, "abs_of_scene_size": 0.0}}
 
 
-def load_room():
+def gold(name):
+    return os.path.join(REPO, "tests", "golden", name)
+
+
+def load_scene(name="room"):
     from raytracing_amd.backend.packer import PackedScene
 
-    gold = os.path.join(REPO, "tests", "golden")
-    sky = np.ascontiguousarray(np.load(os.path.join(gold, "skybox1_rgb8.npz"))["rgb"])
-    return PackedScene.load(os.path.join(gold, "scene_room.npz"), sky_rgb=sky)
+    sky = np.ascontiguousarray(np.load(gold("skybox1_rgb8.npz"))["rgb"])
+    return PackedScene.load(gold(f"scene_{name}.npz"), sky_rgb=sky)
 
 
-def measured_traffic():
-    """HBM bytes per launch of the render kernel on THIS workload, from the committed PMC passes
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside a timed benchmark); None if absent."""
+def profile_json(name):
     try:
-        with open(os.path.join(REPO, "profiles", "r1_hbm_traffic.json")) as fh:
-            return float(json.load(fh)["bytes_per_launch"])
+        with open(os.path.join(REPO, "profiles", name)) as fh:
+            return json.load(fh)
     except Exception:
         return None
 
 
 def algorithmic_flops(st: dict) -> float:
-    return (st["sphere_tests"] * F_SPHERE + st["tri_tests"] * F_TRI + st["shaded_hits"] * F_SHADE
+    return (st["sphere_tests"] * F_SPHERE + st["tri_tests"] * F_TRI + st["bvh_node_tests"] * F_AABB + st["shaded_hits"] * F_SHADE
             + st["paths"] * F_RAYGEN + st["sky_lookups"] * F_SKY)
+
+
+def roofline_of(st: dict, kernel: str, traffic_file: str | None, mode: str = "default") -> dict:
+    launches = max(int(st["launches"]), 1)
+    kernel_s = st["kernel_ms"] * 1e-3 / launches
+    flops_launch = algorithmic_flops(st) / launches
+    achieved = flops_launch / kernel_s / 1e12
+    out = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / PEAK_FP32_VALU_TFLOPS, "frac_basis": "algorithmic FLOPs (tests executed x per-test constants)",
+           "kernel": kernel, "kernel_ms_per_launch": kernel_s * 1e3, "kernel_ms_min": st["kernel_ms_min"], "kernel_ms_max": st["kernel_ms_max"],
+           "flops_per_launch": flops_launch, "rays_per_launch": st["rays"] / launches,
+           "exact_ray_fraction": st["exact_rays"] / max(st["rays"], 1), "refined_hit_fraction": st["refined_hits"] / max(st["rays"], 1),
+           "depth_accept_rel": DEPTH_ACCEPT[mode]["rel"], "depth_accept_abs_of_scene_size": DEPTH_ACCEPT[mode]["abs_of_scene_size"],
+           "traffic": None}
+    prof = profile_json(traffic_file) if traffic_file else None
+    if prof:
+        # committed PMC passes of the same kernel on the same workload (counters cannot be collected inside a timed run)
+        if "hbm_bytes_per_ray" in prof:
+            out["traffic"] = prof["hbm_bytes_per_ray"] * st["rays"] / launches
+            out["hbm"] = {"bound": "hbm", "achieved": out["traffic"] / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": out["traffic"] / kernel_s / 1e9 / PEAK_HBM_GBS}
+        if "executed_fp32_flops_per_ray" in prof:
+            ex = prof["executed_fp32_flops_per_ray"] * st["rays"] / launches / kernel_s / 1e12
+            out["executed_tflops"] = ex
+            out["executed_frac"] = ex / PEAK_FP32_VALU_TFLOPS
+        out["traffic_note"] = f"HBM bytes and executed FLOPs per ray from the PMC passes in profiles/{traffic_file} x this run's rays"
+    return out
 
 
 def cpu_baseline(scene) -> dict:
@@ -90,12 +132,62 @@ def cpu_baseline(scene) -> dict:
             "single_thread_value": rate1, "single_thread_sample": f"{w}x{hgt}, 2 spp ({rays1} rays in {dt1:.2f} s)"}
 
 
+def run_other_configs(be, torch, stream) -> dict:
+    """BASELINE configs[1] (random_spheres 1080p, 64 spp), [3] (room + 1.18 M-triangle mesh, 1080p,
+    128 spp) and one GPU's share of [4] (room + mesh at 3840x2160, 128 of the 1024 spp in batches of
+    16 with the fused tone-map after every batch).  Each is rendered once after a short warm-up, outside
+    the headline's timed region."""
+    from raytracing_amd.post_processing import PostProcessing
+
+    out = {}
+
+    def run(key, workload, scene, W, H, spp, kernel, traffic_file, batch=None, tonemap=False):
+        be.set_scene(scene)
+        acc = torch.zeros((W, H, 3), dtype=torch.float32, device="cuda:0")
+        be.render(W, H, 0, 1, BOUNCES, SEED, accum_ptr=acc.data_ptr(), stream=stream)
+        be.synchronize(stream)
+        acc.zero_()
+        be.reset_stats()
+        torch.cuda.synchronize()
+        pp = PostProcessing(exposure=2, brightness=0.02, contrast=1.1)
+        dst = torch.empty_like(acc)
+        t0 = time.perf_counter()
+        step = batch or spp
+        for s0 in range(0, spp, step):
+            n = min(step, spp - s0)
+            be.render(W, H, s0, n, BOUNCES, SEED, accum_ptr=acc.data_ptr(), stream=stream)
+            if tonemap:
+                be.postprocess(W, H, dst.data_ptr(), src_ptr=acc.data_ptr(), scale=1.0 / (s0 + n), flip_y=True, exposure=2.0,
+                               brightness=0.02, contrast=1.1, stream=stream)
+        be.synchronize(stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = be.stats()
+        out[key] = {"workload": workload, "value": st["rays"] / dt, "unit": "rays/s", "samples_per_s": st["paths"] / dt,
+                    "ms": dt * 1e3, "rays_per_path": st["rays"] / max(st["paths"], 1),
+                    "box_tests_per_ray": st["bvh_node_tests"] / max(st["rays"], 1), "triangle_tests_per_ray": st["tri_tests"] / max(st["rays"], 1),
+                    "finite": bool(torch.isfinite(acc).all().item()), "roofline": roofline_of(st, kernel, traffic_file)}
+        del acc, dst
+
+    run("c2", "scenes/random_spheres.py (seed 7) 1920x1080, 64 spp, 8 bounces (BASELINE configs[1])",
+        load_scene("random_spheres_seed7"), 1920, 1080, 64, "rt::k_render<0,true,false>", None)
+    base = load_scene("room_horse")
+    big = base.with_subdivided_mesh(base.n_meshes - 1, 6)
+    run("c4", "room + chess_horse.obj split to 1.18 M triangles, host-built hierarchy, 1920x1080, 128 spp, 8 bounces (BASELINE configs[3])",
+        big, 1920, 1080, 128, "rt::k_render<2,true,false>", "r2_bvh_counters.json")
+    run("c5_one_gpu_share", "room + 1.18 M-triangle mesh, 3840x2160, 128 of 1024 spp (one of 8 ranks) in batches of 16, fused tone-map "
+        "after every batch (BASELINE configs[4], one GPU's share; the 8-GPU merge is one all-reduce of 99.5 MB)",
+        big, 3840, 2160, 128, "rt::k_render<2,true,false>", "r2_bvh_counters.json", batch=16, tonemap=True)
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     a = ap.parse_args()
 
     import torch
@@ -122,17 +214,21 @@ def main() -> None:
     from raytracing_amd.backend.lib import HipBackend
     from raytracing_amd.distributed import DistributedRenderer
 
-    scene = load_room()
+    scene = load_scene("room")
     be = HipBackend(local_rank)
     be.set_scene(scene)
     accum = torch.zeros((WIDTH, HEIGHT, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     dr = DistributedRenderer(be, accum)
+    # the merge belongs to the library (rt_merge over its own RCCL communicator); torch.distributed is the fallback
+    library_merge = dr.use_library_merge() if (world > 1 and backend_name == "nccl") else False
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
+    def step(strict=False):
         accum.zero_()
-        dr.render_local(WIDTH, HEIGHT, SPP, BOUNCES, SEED, stream=stream)
-        dr.merge()
+        begin, count = dr.render_local(WIDTH, HEIGHT, SPP, BOUNCES, SEED, stream=stream) if not strict else (0, 0)
+        if strict:
+            be.render(WIDTH, HEIGHT, 0, SPP, BOUNCES, SEED, accum_ptr=accum.data_ptr(), stream=stream, strict_depth=True)
+        dr.merge(stream)
 
     def fence():
         if world > 1:
@@ -151,30 +247,47 @@ def main() -> None:
     fence()
     say("warm-up done")
     be.reset_stats()
+    # per-step device time: events on the launch stream around every step, read after the final fence (no host
+    # synchronisation inside the timed region)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for k in range(a.steps):
+        ev[k][0].record()
         step()
+        ev[k][1].record()
     fence()
     dt = time.perf_counter() - t0
     say("timed steps done")
     st = be.stats()   # this rank's counters over the timed steps
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in ev] or [0.0]
 
     # whole-job numbers: sum of rays over ranks, max of time over ranks
     tot = torch.tensor([float(st["rays"]), float(st["paths"]), algorithmic_flops(st), st["kernel_ms"]],
                        dtype=torch.float64, device=f"cuda:{local_rank}")
-    tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tmax = torch.tensor([dt, max(step_ms), st["kernel_ms_max"]], dtype=torch.float64, device=f"cuda:{local_rank}")
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     rays_all, paths_all, flops_all, kms_all = [float(x) for x in tot.tolist()]
-    dt_all = float(tmax.item())
+    dt_all, step_max_all, kernel_max_all = [float(x) for x in tmax.tolist()]
     say("reduced")
 
+    strict_line = None
+    if world == 1:
+        for _ in range(1):
+            step(strict=True)
+        fence()
+        be.reset_stats()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step(strict=True)
+        fence()
+        dts = time.perf_counter() - t1
+        sst = be.stats()
+        strict_line = {"value": sst["rays"] / dts, "ms_per_step": dts / max(a.steps, 1) * 1e3, "roofline": roofline_of(sst, "rt::k_render<1,true,true>", None, "strict")}
+
     if rank == 0:
-        launches = max(int(st["launches"]), 1)
-        kernel_s = st["kernel_ms"] * 1e-3 / launches            # average launch duration, this rank
-        flops_launch = algorithmic_flops(st) / launches
-        achieved = flops_launch / kernel_s / 1e12
+        roof = roofline_of(st, "rt::k_render<1,true,false>", "r2_room_counters.json")
         out = {
             "metric": "rays/sec at 1/2/4/8 MI355X, room.py 1080p; % of FP32 VALU peak",
             "value": rays_all / dt_all,
@@ -190,18 +303,24 @@ def main() -> None:
             "data": "synthetic: upstream room scene tables + decoded sky image (tests/golden), Philox sample stream",
             "config": {"workload": "scenes/room.py 1920x1080, 256 spp, 8 bounces, skybox (BASELINE configs[2])",
                        "width": WIDTH, "height": HEIGHT, "spp": SPP, "max_bounces": BOUNCES,
-                       "parallelism": f"spp-shard x{world} + all-reduce" if world > 1 else "single GPU"},
+                       "parallelism": f"spp-shard x{world} + all-reduce" if world > 1 else "single GPU",
+                       "merge": ("rt_merge (RCCL, library communicator)" if library_merge else "torch.distributed all_reduce") if world > 1 else "none"},
             "samples_per_s": paths_all / dt_all,
             "rays_per_path": rays_all / max(paths_all, 1.0),
-            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": measured_traffic() if world == 1 else None,
-                         "traffic_note": "HBM bytes per launch at N=1, PMC passes in profiles/r1_hbm_traffic.json (2*FETCH_SIZE + WRITE_SIZE)",
-                         "kernel": "rt::k_render", "kernel_ms_per_launch": kernel_s * 1e3,
-                         "flops_per_launch": flops_launch,
-                         "exact_ray_fraction": st["exact_rays"] / max(st["rays"], 1),
-                         "refined_hit_fraction": st["refined_hits"] / max(st["rays"], 1)},
+            "step_ms_min": min(step_ms), "step_ms_median": statistics.median(step_ms), "step_ms_max": step_max_all,
+            "kernel_ms_min": st["kernel_ms_min"], "kernel_ms_max": kernel_max_all,
+            "roofline": roof,
         }
+        if world > 1 and not library_merge and dr.library_merge_error:
+            out["config"]["merge_note"] = dr.library_merge_error[:200]
+        if strict_line:
+            out["value_strict"] = strict_line["value"]
+            out["strict"] = strict_line
+        if world == 1 and not a.no_other_configs:
+            try:
+                out["other_configs"] = run_other_configs(be, torch, stream)
+            except Exception as e:   # noqa: BLE001 - the headline line must come out whatever happens to the extras
+                out["other_configs"] = {"error": repr(e)[:300]}
         if not a.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out), flush=True)

@@ -143,8 +143,10 @@ typedef struct rt_stats {
     uint64_t exact_rays;           /* rays whose contenders were settled in double precision (second pass or whole-scene scan) */
     uint64_t refined_hits;         /* hits whose winning primitive was re-evaluated in double precision */
     uint64_t sky_lookups, shaded_hits;
-    double kernel_ms;              /* device time of the dominant kernel, summed over launches */
+    double kernel_ms;              /* device time of the dominant kernel (rt_render: the render kernel alone, without the
+                                      short fold of the per-job slots that follows it), summed over launches */
     uint64_t launches;
+    double kernel_ms_min, kernel_ms_max;   /* shortest and longest single launch (0 without launches): shows an outlier a mean hides */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -224,6 +226,22 @@ int rt_accum_read(rt_ctx *ctx, float *host_w_h_3);      /* blocking copy of the 
  * Asynchronous on `stream`; rt_synchronize waits. */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, float *accum_dev, void *stream);
 int rt_synchronize(rt_ctx *ctx, void *stream);
+
+/* Merge across GPUs.  Upstream has one process and one buffer (render_result.py:24-27: every tile
+ * adds into the same arr); with one process per GPU, each rendering its share of the samples into
+ * its own buffer, the same sum is ONE all-reduce of the (W,H,3) float32 buffers - RCCL over xGMI,
+ * issued by this library (PyTorch is not needed for it).
+ *   rt_comm_unique_id : rank 0 makes the 128-byte id and hands it to the other ranks by any means
+ *                       (a file, MPI, torch.distributed.broadcast, ...).  Needs no context.
+ *   rt_comm_init      : every rank, once per context, with the context's GPU as its RCCL device.
+ *                       n_ranks = 1 with a NULL id makes rt_merge a no-op without opening RCCL.
+ *   rt_merge          : in-place sum over the ranks of accum_dev (NULL = the context's buffer),
+ *                       asynchronous on `stream`; every rank must call it with the same size.
+ * librccl.so is opened on first use; RT_ERR_UNSUPPORTED when it cannot be. */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(void *out_128_bytes);
+int rt_comm_init(rt_ctx *ctx, int32_t n_ranks, int32_t rank, const void *unique_id_128_bytes);
+int rt_merge(rt_ctx *ctx, float *accum_dev, int32_t width, int32_t height, void *stream);
 
 /* PostProcessing.process (src/post_processing/post_processing.py:35-82) on the device, fused into two
  * passes over the image: exposure (:47), contrast / brightness with its clip (:56), saturation (:58-60),

@@ -23,6 +23,7 @@ RT_ERR_STOPPED = 5
 # every symbol include/raytracing_amd.h declares
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
+           "rt_comm_unique_id", "rt_comm_init", "rt_merge",
            "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms",
            "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_build_bvh_threads", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
@@ -46,7 +47,7 @@ class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("sphere_tests", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("aabb_tests", C.c_uint64), ("bvh_node_tests", C.c_uint64), ("exact_rays", C.c_uint64),
                 ("refined_hits", C.c_uint64), ("sky_lookups", C.c_uint64), ("shaded_hits", C.c_uint64),
-                ("kernel_ms", C.c_double), ("launches", C.c_uint64)]
+                ("kernel_ms", C.c_double), ("launches", C.c_uint64), ("kernel_ms_min", C.c_double), ("kernel_ms_max", C.c_double)]
 
     def as_dict(self) -> dict:
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -86,6 +87,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_accum_read.argtypes = [vp, fp]
     lib.rt_render.argtypes = [vp, C.POINTER(RtRenderParams), vp, vp]
     lib.rt_synchronize.argtypes = [vp, vp]
+    lib.rt_comm_unique_id.argtypes = [vp]
+    lib.rt_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    lib.rt_merge.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.rt_request_stop.argtypes = [vp]
     lib.rt_clear_stop.argtypes = [vp]
     lib.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
@@ -121,6 +125,7 @@ class HipBackend:
         self.device = device
         self._scene_keepalive = None
         self.size = None
+        self.comm_ranks = 0   # > 0 once comm_init has run
 
     # -- plumbing -------------------------------------------------------------------------------
     def _check(self, st: int) -> None:
@@ -212,6 +217,26 @@ class HipBackend:
         entry = self.lib.rt_postprocess_noalloc if no_alloc else self.lib.rt_postprocess
         self._check(entry(self.handle, C.c_void_p(src_ptr or None), width, height, scale, int(bool(flip_y)),
                           C.byref(p), C.c_void_p(dst_ptr), C.c_void_p(stream or None)))
+
+    # -- merge across GPUs (RCCL, issued by the library) ------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte communicator id: rank 0 makes it and hands it to every other rank."""
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        st = lib.rt_comm_unique_id(buf)
+        if st != 0:
+            raise BackendError(st, (lib.rt_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, n_ranks: int, rank: int, unique_id: Optional[bytes] = None) -> None:
+        buf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.lib.rt_comm_init(self.handle, n_ranks, rank, buf))
+        self.comm_ranks = n_ranks
+
+    def merge(self, width: int, height: int, accum_ptr: int = 0, stream: int = 0) -> None:
+        """In-place sum of the (W, H, 3) float32 buffers of all ranks (0 = the context's own buffer)."""
+        self._check(self.lib.rt_merge(self.handle, C.c_void_p(accum_ptr or None), width, height, C.c_void_p(stream or None)))
 
     def synchronize(self, stream: int = 0) -> None:
         self._check(self.lib.rt_synchronize(self.handle, C.c_void_p(stream or None)))

@@ -3,6 +3,8 @@
 // entry.  gfx950 only; built with -ffp-contract=off (the exact double-precision code must round
 // like upstream's Python floats, and the float32 code spells out every fused multiply-add).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is opened when rt_comm_* is first called
 
 #include <algorithm>
 #include <atomic>
@@ -106,6 +108,8 @@ struct rt_ctx {
     std::vector<EventPair> timed;        // recorded around render launches, not yet read
     std::vector<EventPair> spare_events; // read and ready for reuse (events are created once, not per launch)
     double kernel_ms = 0; uint64_t launches = 0;
+    double kernel_ms_min = 0, kernel_ms_max = 0; uint64_t launches_timed = 0;
+    ncclComm_t comm = nullptr; int comm_ranks = 1, comm_rank = 0;   // rt_comm_init
     uint64_t paths_launched = 0;         // paths of rt_render's single-kernel launches: rectangle x samples, known here, not counted on the device
 };
 
@@ -130,6 +134,39 @@ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x
 double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 double norm(V3 a) { return std::sqrt(dot(a, a)); }
 double norm1(V3 a) { return std::fabs(a.x) + std::fabs(a.y) + std::fabs(a.z); }
+
+// RCCL is opened on first use (dlopen), so that single-GPU users of this library neither link nor
+// load it.  Only four entry points are needed.
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*get_unique_id)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*comm_init_rank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*all_reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*error_string)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { const char *e = dlerror(); r.why = std::string("cannot open librccl.so: ") + (e ? e : "?"); return; }
+        r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.handle, "ncclGetUniqueId");
+        r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(r.handle, "ncclCommInitRank");
+        r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.handle, "ncclCommDestroy");
+        r.all_reduce = (decltype(r.all_reduce))dlsym(r.handle, "ncclAllReduce");
+        r.error_string = (decltype(r.error_string))dlsym(r.handle, "ncclGetErrorString");
+        if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce) { r.why = "librccl.so lacks a required symbol"; r.handle = nullptr; }
+    });
+    return r;
+}
+
+const char *rccl_error(ncclResult_t e) { Rccl &r = rccl(); return r.error_string ? r.error_string(e) : "RCCL error"; }
 
 FastDiv make_fast_div(uint32_t d) {
     FastDiv f{}; f.d = d;
@@ -188,6 +225,7 @@ int rt_destroy(rt_ctx *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    if (ctx->comm) { (void)rccl().comm_destroy(ctx->comm); ctx->comm = nullptr; }
     for (auto *v : {&ctx->timed, &ctx->spare_events})
         for (auto &e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete ctx;
@@ -975,6 +1013,63 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     return RT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// merge across GPUs: one RCCL all-reduce of the accumulation buffers
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+
+}  // namespace
+
+extern "C" {
+
+int rt_comm_unique_id(void *out_128_bytes) {
+    if (!out_128_bytes) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_comm_unique_id: NULL argument");
+    Rccl &r = rccl();
+    if (!r.handle) return fail(nullptr, RT_ERR_UNSUPPORTED, "%s", r.why.c_str());
+    static_assert(sizeof(ncclUniqueId) == RT_COMM_ID_BYTES, "rt_comm_unique_id hands out an ncclUniqueId");
+    ncclUniqueId id;
+    const ncclResult_t e = r.get_unique_id(&id);
+    if (e != ncclSuccess) return fail(nullptr, RT_ERR_HIP, "ncclGetUniqueId failed: %s", rccl_error(e));
+    std::memcpy(out_128_bytes, &id, sizeof id);
+    return RT_OK;
+}
+
+int rt_comm_init(rt_ctx *c, int32_t n_ranks, int32_t rank, const void *unique_id_128_bytes) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, RT_ERR_INVALID_ARG, "rt_comm_init: rank %d of %d", rank, n_ranks);
+    if (c->comm) return fail(c, RT_ERR_INVALID_ARG, "rt_comm_init: this context already has a communicator");
+    if (n_ranks > 1 && !unique_id_128_bytes) return fail(c, RT_ERR_INVALID_ARG, "rt_comm_init: more than one rank needs rank 0's id");
+    c->comm_ranks = n_ranks; c->comm_rank = rank;
+    if (!unique_id_128_bytes) return RT_OK;   // one rank, no id given: rt_merge has nothing to do and RCCL stays unopened
+    Rccl &r = rccl();
+    if (!r.handle) return fail(c, RT_ERR_UNSUPPORTED, "%s", r.why.c_str());
+    HIP_TRY(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id_128_bytes, sizeof id);
+    const ncclResult_t e = r.comm_init_rank(&c->comm, n_ranks, id, rank);
+    if (e != ncclSuccess) { c->comm = nullptr; return fail(c, RT_ERR_HIP, "ncclCommInitRank failed: %s", rccl_error(e)); }
+    return RT_OK;
+}
+
+int rt_merge(rt_ctx *c, float *accum_dev, int32_t width, int32_t height, void *stream) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28)) return fail(c, RT_ERR_INVALID_ARG, "rt_merge: bad size %d x %d", width, height);
+    float *buf = accum_dev;
+    if (!buf) {
+        if (c->acc_w != width || c->acc_h != height) return fail(c, RT_ERR_INVALID_ARG, "rt_merge: context buffer is %dx%d, not %dx%d", c->acc_w, c->acc_h, width, height);
+        buf = c->accum.as<float>();
+    }
+    if (c->comm_ranks == 1 && !c->comm) return RT_OK;   // nothing to merge with
+    if (!c->comm) return fail(c, RT_ERR_INVALID_ARG, "rt_merge: %d ranks but no communicator (rt_comm_init)", c->comm_ranks);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const ncclResult_t e = rccl().all_reduce(buf, buf, (size_t)width * height * 3, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream);
+    if (e != ncclSuccess) return fail(c, RT_ERR_HIP, "ncclAllReduce failed: %s", rccl_error(e));
+    return RT_OK;
+}
+
 int rt_synchronize(rt_ctx *c, void *stream) {
     if (!c) return RT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -988,12 +1083,23 @@ int rt_clear_stop(rt_ctx *c) { if (!c) return RT_ERR_INVALID_ARG; c->stop.store(
 static int drain_events(rt_ctx *c) {
     std::vector<EventPair> evs;
     { std::lock_guard<std::mutex> g(c->mu); evs.swap(c->timed); }
-    double ms_sum = 0;
+    double ms_sum = 0, ms_min = INFINITY, ms_max = 0; uint64_t n = 0;
     for (auto &e : evs) {
         float ms = 0;
-        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) ms_sum += ms;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            ms_sum += ms; ms_min = std::min(ms_min, (double)ms); ms_max = std::max(ms_max, (double)ms); ++n;
+        }
     }
-    { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms += ms_sum; c->spare_events.insert(c->spare_events.end(), evs.begin(), evs.end()); }
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        c->kernel_ms += ms_sum;
+        if (n) {
+            c->kernel_ms_min = c->launches_timed ? std::min(c->kernel_ms_min, ms_min) : ms_min;
+            c->kernel_ms_max = std::max(c->kernel_ms_max, ms_max);
+            c->launches_timed += n;
+        }
+        c->spare_events.insert(c->spare_events.end(), evs.begin(), evs.end());
+    }
     return RT_OK;
 }
 
@@ -1008,7 +1114,8 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     out->rays = v[kStatRays]; out->paths = v[kStatPaths]; out->sphere_tests = v[kStatSphTests]; out->tri_tests = v[kStatTriTests];
     out->aabb_tests = 0; out->bvh_node_tests = v[kStatBvhNodes]; out->exact_rays = v[kStatExact]; out->refined_hits = v[kStatRefine];
     out->sky_lookups = v[kStatSky]; out->shaded_hits = v[kStatShaded];
-    { std::lock_guard<std::mutex> g(c->mu); out->kernel_ms = c->kernel_ms; out->launches = c->launches; out->paths += c->paths_launched; }
+    { std::lock_guard<std::mutex> g(c->mu); out->kernel_ms = c->kernel_ms; out->launches = c->launches; out->paths += c->paths_launched;
+      out->kernel_ms_min = c->kernel_ms_min; out->kernel_ms_max = c->kernel_ms_max; }
     return RT_OK;
 }
 
@@ -1031,7 +1138,7 @@ int rt_reset_stats(rt_ctx *c) {
     HIP_TRY(c, hipDeviceSynchronize());
     drain_events(c);
     HIP_TRY(c, hipMemset(c->stats.p, 0, sizeof(unsigned long long) * (kStatCount + kProfCount)));
-    { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms = 0; c->launches = 0; c->paths_launched = 0; }
+    { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms = 0; c->launches = 0; c->paths_launched = 0; c->kernel_ms_min = c->kernel_ms_max = 0; c->launches_timed = 0; }
     return RT_OK;
 }
 

@@ -40,6 +40,8 @@ class DistributedRenderer:
         self.dist = dist
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.library_merge = False
+        self.library_merge_error = None
 
     def render_local(self, width: int, height: int, total_samples: int, max_bounces: int, seed: int,
                      sample_offset: int = 0, stream: int = 0) -> Tuple[int, int]:
@@ -49,14 +51,45 @@ class DistributedRenderer:
                                 accum_ptr=self.accum.data_ptr(), stream=stream)
         return begin, count
 
-    def merge(self) -> None:
-        """Sum the per-rank buffers in place on every rank."""
-        if self.world > 1:
+    def use_library_merge(self) -> bool:
+        """Give the backend its own RCCL communicator (``rt_comm_init``), so that ``merge`` is the
+        library's ``rt_merge`` and PyTorch is left with the tensor hand-off only.  Rank 0 makes the
+        communicator id; ``torch.distributed`` merely carries its 128 bytes to the other ranks (any
+        channel would do).  Returns False, and leaves ``merge`` on ``torch.distributed``, when the
+        backend has no such entry points or RCCL cannot be set up (every rank takes the same branch)."""
+        if not hasattr(self.backend, "comm_init"):
+            return False
+        ok = True
+        try:
+            if self.world == 1:
+                self.backend.comm_init(1, 0, None)
+            else:
+                box = [type(self.backend).comm_unique_id() if self.rank == 0 else None]
+                self.dist.broadcast_object_list(box, src=0, group=self.group)
+                self.backend.comm_init(self.world, self.rank, box[0])
+        except Exception as e:   # noqa: BLE001 - whatever went wrong, the torch path still works
+            self.library_merge_error = repr(e)
+            ok = False
+        if self.world > 1:       # all ranks or none
+            flags = [None] * self.world
+            self.dist.all_gather_object(flags, ok, group=self.group)
+            ok = all(flags)
+        self.library_merge = ok
+        return ok
+
+    def merge(self, stream: int = 0) -> None:
+        """Sum the per-rank buffers in place on every rank: one all-reduce (RCCL over xGMI), issued by
+        the library (``rt_merge``) after ``use_library_merge``, else through ``torch.distributed``."""
+        if self.world <= 1:
+            return
+        if getattr(self, "library_merge", False):
+            w, h = int(self.accum.shape[0]), int(self.accum.shape[1])
+            self.backend.merge(w, h, accum_ptr=self.accum.data_ptr(), stream=stream)
+        else:
             self.dist.all_reduce(self.accum, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def render(self, width: int, height: int, total_samples: int, max_bounces: int, seed: int,
                sample_offset: int = 0, stream: int = 0):
         self.render_local(width, height, total_samples, max_bounces, seed, sample_offset, stream)
-        self.backend.synchronize(stream)
-        self.merge()
+        self.merge(stream)   # on the render's stream: ordered behind the kernels, no host synchronisation in between
         return self.accum

@@ -80,3 +80,52 @@ def test_gloo_merge_equals_single_rank(tmp_path, world):
     for r in range(world):
         got = np.load(tmp_path / f"r{r}.npy")
         assert np.array_equal(got, want)   # every rank holds the full sum; integers, so exact
+
+
+class FakeCommBackend(FakeBackend):
+    """A backend that brings its own communicator, as HipBackend does (rt_comm_init / rt_merge):
+    here the "library" all-reduce is gloo's, so the hand-shake around it can be checked on CPU."""
+    fail_on_rank = None
+
+    @staticmethod
+    def comm_unique_id():
+        return bytes(range(128))
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        if rank == FakeCommBackend.fail_on_rank:
+            raise RuntimeError("no RCCL here")
+        self.comm = (n_ranks, rank, unique_id)
+
+    def merge(self, width, height, accum_ptr=0, stream=0):
+        assert accum_ptr == self.accum.data_ptr() and (width, height) == (W, H)
+        self.merged_by_library = True
+        dist.all_reduce(self.accum)
+
+
+def _comm_worker(rank, world, port, out_dir, fail_on_rank):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    FakeCommBackend.fail_on_rank = fail_on_rank
+    accum = torch.zeros((W, H, 3), dtype=torch.float32)
+    be = FakeCommBackend(accum)
+    dr = DistributedRenderer(be, accum)
+    ok = dr.use_library_merge()
+    assert ok == (fail_on_rank is None)                      # all ranks or none
+    if ok:
+        assert be.comm == (world, rank, bytes(range(128)))   # rank 0's id reached every rank
+    merged = dr.render(W, H, TOTAL, 8, 1234)
+    assert getattr(be, "merged_by_library", False) == ok
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), merged.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_on_rank", [None, 1])
+def test_library_merge_handshake(tmp_path, fail_on_rank):
+    """use_library_merge: the communicator id travels from rank 0 to all, the ranks agree on whether
+    the library merges (a rank that cannot set RCCL up sends everyone to the torch.distributed path),
+    and the merged sums are the same either way."""
+    mp.spawn(_comm_worker, args=(2, _free_port(), str(tmp_path), fail_on_rank), nprocs=2, join=True)
+    want = _value(range(0, TOTAL))
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), want)

@@ -1005,3 +1005,40 @@ def test_render_path_segments_against_oracle(backend, scene, W, H, spp, b, step,
     else:
         assert within_loose.all() and rel0.max() <= 2e-4 and frac < 1e-3, \
             f"max relative depth error {rel_all.max():.3e}, {frac:.2e} of segments above 1e-5, {int((~within_loose).sum())} outside the stated bound"
+
+
+def test_library_merge_one_rank(backend):
+    """rt_comm_unique_id / rt_comm_init / rt_merge with a real RCCL communicator of ONE rank (all a
+    one-GPU box can hold: RCCL refuses two ranks on one device): the all-reduce over one rank leaves
+    the buffer as it is, on the context's own buffer and on a caller's tensor; sizes are checked.
+    More than one rank is exercised by bench.py --gpus N on a multi-GPU node only."""
+    import torch
+
+    from raytracing_amd.backend.lib import BackendError, HipBackend
+    from raytracing_amd.distributed import DistributedRenderer
+
+    be = HipBackend(0)
+    _ = _set(be, "room")
+    W, H = 64, 36
+    be.resize(W, H)
+    be.render(W, H, 0, 2, 4, 7)
+    be.synchronize()
+    before = be.read()
+    be.merge(W, H)                                   # no communicator, one rank: a no-op
+    uid = HipBackend.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    be.comm_init(1, 0, uid)
+    be.merge(W, H)
+    t = torch.arange(W * H * 3, dtype=torch.float32, device="cuda:0").reshape(W, H, 3)
+    be.merge(W, H, accum_ptr=t.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    be.synchronize()
+    assert np.array_equal(be.read(), before)
+    assert torch.equal(t.cpu(), torch.arange(W * H * 3, dtype=torch.float32).reshape(W, H, 3))
+    with pytest.raises(BackendError):
+        be.merge(W + 1, H)                           # not the context buffer's size
+    with pytest.raises(BackendError):
+        be.comm_init(1, 0, uid)                      # one communicator per context
+    dr = DistributedRenderer(be, t)
+    assert dr.world == 1 and dr.merge() is None
+    be.close()
