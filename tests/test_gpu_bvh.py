@@ -221,6 +221,60 @@ def test_progressive_batches_and_device_tonemap(backend):
     assert float(previews[0].mean()) > 0 and len(previews) == 3
 
 
+def test_config5_at_full_size_eight_rank_shares(backend):
+    """BASELINE config 5 AT SIZE on one GPU: room + the 1.18 M-triangle mesh at 3840x2160, 1024 spp,
+    8 bounces.  The eight rank shares `shard_samples(1024, r, 8)` are rendered progressively (batches of
+    16 samples) into eight buffers - what eight GPUs would hold before the merge - and summed in rank
+    order, which is what the all-reduce computes; the sum must equal ONE 1024-spp render of the same
+    frame (same global sample indices -> same paths; float32 summation order is the only difference).
+    Every value finite and non-negative.  Then the device tone-map of upstream's main.py chain
+    (exposure 2, brightness 0.02, contrast 1.1) straight from the merged buffer against the numpy
+    chain on the read-back, 2e-5 absolute."""
+    import torch
+
+    from raytracing_amd.distributed import shard_samples
+    from raytracing_amd.post_processing import PostProcessing
+
+    base = h.packed_scene("room_horse")
+    backend.set_scene(base.with_subdivided_mesh(base.n_meshes - 1, 6))
+    W, H, spp, b, seed, ranks = 3840, 2160, 1024, 8, 2025, 8
+    stream = torch.cuda.current_stream().cuda_stream
+    one = torch.zeros((W, H, 3), dtype=torch.float32, device="cuda:0")
+    backend.reset_stats()
+    backend.render(W, H, 0, spp, b, seed, accum_ptr=one.data_ptr(), stream=stream)
+    backend.synchronize(stream)
+    st_one = backend.stats()
+    merged = torch.zeros_like(one)
+    share = torch.zeros_like(one)
+    backend.reset_stats()
+    for r in range(ranks):
+        begin, count = shard_samples(spp, r, ranks)
+        share.zero_()
+        for s0 in range(begin, begin + count, 16):
+            backend.render(W, H, s0, min(16, begin + count - s0), b, seed, accum_ptr=share.data_ptr(), stream=stream)
+        backend.synchronize(stream)
+        merged += share                      # rank order, as a ring all-reduce's partial sums would not be - hence the tolerance
+    torch.cuda.synchronize()
+    st_shares = backend.stats()
+    assert st_one["paths"] == st_shares["paths"] == W * H * spp
+    assert st_one["rays"] == st_shares["rays"]                      # the same paths, segment for segment
+    assert bool(torch.isfinite(merged).all()) and float(merged.min()) >= 0.0
+    scale = float(one.max())
+    err = float((merged - one).abs().max())
+    rel = float(((merged - one).abs() / one.clamp_min(1e-3 * scale)).max())
+    print(f"\nconfig 5 at size: {st_one['rays']} rays per render, max |sum of shares - one render| = {err:.3e} (sums up to {scale:.1f}), relative {rel:.3e}")
+    assert rel <= 2e-5, rel
+    # tone-map on the device, straight from the merged sums (pass count and display flip folded in)
+    pp = PostProcessing(exposure=2, brightness=0.02, contrast=1.1)
+    dev = torch.empty_like(merged)
+    backend.postprocess(W, H, dev.data_ptr(), src_ptr=merged.data_ptr(), scale=1.0 / spp, flip_y=True, exposure=2.0, brightness=0.02,
+                        contrast=1.1, stream=stream)
+    torch.cuda.synchronize()
+    host = pp.process((merged.cpu().numpy().astype(np.float64) / spp)[:, ::-1])
+    assert np.abs(dev.cpu().numpy() - host).max() < 2e-5
+    del one, merged, share, dev
+
+
 def test_wavefront_form_traces_the_same_paths(backend, monkeypatch):
     """The optional wavefront form (generate / extend / shade / resolve kernels) runs the same device
     functions as the single render kernel, so images agree up to float32 summation order and the
