@@ -387,7 +387,7 @@ def cmd_image(which, W, H, spp, bounces, procs, tag):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["kat", "scenes", "rays", "rays_horse", "room_image", "spheres_image", "all"])
+    ap.add_argument("what", choices=["kat", "scenes", "rays", "rays_horse", "room_image", "room_image_offedge", "spheres_image", "all"])
     ap.add_argument("--procs", type=int, default=6)
     a = ap.parse_args()
     if a.what in ("scenes", "all"):
@@ -400,6 +400,10 @@ def main():
         cmd_rays(cases=(("room_horse", 64, 36, 1, 6, 1),))
     if a.what in ("room_image", "all"):
         cmd_image("room", 96, 54, 8, 8, a.procs, "room_96x54_8spp_8b")
+    if a.what in ("room_image_offedge", "all"):
+        # width - height odd: no pixel centre lies on the lines u = +-v onto which the cube's four depth-wise
+        # edges project (at 96x54 the pixels with x - y = 21 sit exactly on them)
+        cmd_image("room", 100, 57, 8, 8, a.procs, "room_100x57_8spp_8b")
     if a.what in ("spheres_image", "all"):
         cmd_image("random_spheres", 320, 180, 16, 4, a.procs, "random_spheres_320x180_16spp_4b")
 
