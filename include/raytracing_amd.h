@@ -100,7 +100,8 @@ enum {
     RT_SCENE_NO_PAIR_ROWS = 1,     /* every triangle a table row of its own (no parallelogram rows) */
     RT_SCENE_NO_COMPACT_ROWS = 2,  /* no compact rows for parallelograms in axis-perpendicular planes */
     RT_SCENE_NO_LINEAR_SPLIT = 4,  /* hierarchy scenes: scene-sized triangles go into the hierarchy too */
-    RT_SCENE_NO_LDS_TOP = 8        /* hierarchy scenes: top levels read from memory instead of LDS */
+    RT_SCENE_NO_LDS_TOP = 8,       /* hierarchy scenes: top levels read from memory instead of LDS */
+    RT_SCENE_NO_BOX_ROWS = 16      /* no box rows (axis-aligned boxes whose faces are tested with one slab test) */
 };
 
 /* Depth-first ("threaded") BVH node: if the ray misses the box, or after a leaf has been
@@ -285,6 +286,12 @@ int rt_reset_stats(rt_ctx *ctx);
  * out[5*s + i] = uniform i (0..4) of segment s of path (pixel, sample) under `seed`, computed ON THE
  * DEVICE: one Philox4x32-10 block per path segment, five 24-bit fields each. */
 int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t seed, int32_t n_segments, float *out_host);
+
+/* How rt_set_scene laid the current scene's triangles out (no upstream counterpart; tests and tuning):
+ * out[0] parallelogram rows (padded), [1] of which in general position, [2..4] compact rows per axis
+ * x, y, z (padded to even), [5] single-triangle rows (padded), [6] boxes, [7] hierarchy nodes;
+ * n_out >= 8.  *box_slack (optional) = the largest distance of a true box face from its ideal one. */
+int rt_debug_scene_layout(rt_ctx *ctx, int32_t *out, int32_t n_out, float *box_slack);
 
 /* Parity / diagnostic hook: traces n_paths whole paths, one device thread each, with the same
  * device functions the render kernel runs (Camera.get_ray + Renderer.raytrace, camera.py:39-50,

@@ -70,6 +70,24 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define I_FMA_MOD(i)   "v_fma_f32 %" #i ", -%" #i ", |%16|, -%17\n"
 #define I_BFE(i)       "v_bfe_u32 %" #i ", %" #i ", 3, 24\n"
 #define I_EXP(i)       "v_exp_f32 %" #i ", %" #i "\n"
+#define I_BFI(i)       "v_bfi_b32 %" #i ", %16, %" #i ", %17\n"
+#define I_ADD3(i)      "v_add3_u32 %" #i ", %" #i ", %16, %17\n"
+#define I_OR3(i)       "v_or3_b32 %" #i ", %" #i ", %16, %17\n"
+#define I_XAD(i)       "v_xad_u32 %" #i ", %" #i ", %16, %17\n"
+#define I_LSHR(i)      "v_lshrrev_b32 %" #i ", 3, %" #i "\n"
+#define I_PERM(i)      "v_perm_b32 %" #i ", %" #i ", %16, %17\n"
+#define I_ALIGNBIT(i)  "v_alignbit_b32 %" #i ", %" #i ", %16, 7\n"
+#define I_MAXU(i)      "v_max_u32 %" #i ", %16, %" #i "\n"
+#define I_SUBU(i)      "v_sub_u32 %" #i ", %16, %" #i "\n"
+#define I_MED3F(i)     "v_med3_f32 %" #i ", %" #i ", %16, %17\n"
+#define I_FLOOR(i)     "v_floor_f32 %" #i ", %" #i "\n"
+#define I_FRACT(i)     "v_fract_f32 %" #i ", %" #i "\n"
+#define I_CVT_UB(i)    "v_cvt_f32_ubyte1 %" #i ", %" #i "\n"
+#define I_CVT_FU(i)    "v_cvt_u32_f32 %" #i ", %" #i "\n"
+#define I_LDEXP(i)     "v_ldexp_f32 %" #i ", %" #i ", 3\n"
+#define I_ADD_DPP(i)   "v_add_f32_dpp %" #i ", %" #i ", %16 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define I_MUL_CLAMP(i) "v_mul_f32_e64 %" #i ", %16, %" #i " clamp\n"
+#define I_AND_SDWA(i)  "v_and_b32_sdwa %" #i ", %16, %" #i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
 // select patterns (per GROUP as written)
 #define I_CND32_FMA(i)   "v_cndmask_b32 %" #i ", %" #i ", %16, vcc\nv_fma_f32 %" #i ", %" #i ", %16, %17\n"
 #define I_CND32_2FMA(i)  "v_cndmask_b32 %" #i ", %" #i ", %16, vcc\nv_fma_f32 %" #i ", %" #i ", %16, %17\nv_fma_f32 %" #i ", %" #i ", %16, %17\n"
@@ -89,7 +107,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum Op { FMA_VVV, FMA_VSV, FMA_VCC, FMA_SELF, FMAC, MUL_S, MUL_V, ADD_V, MIN_V, MAX_S, MOV, CNDMASK, CNDMASK_S, AND_OR, MED3U, MINU,
           CMP_VCC, CMP_SGPR, RCP, RSQ, SQRT, MUL_LO, MUL_HI, MAD_U24, XOR, LSHL_ADD, CVT_U, READLANE, PK_FMA, PK_MUL, PK_ADD,
-          FMA64, MAD64, FMA_SALU, FMA_2SALU, FMA_DEP, CNDMASK_VCCSET, CNDMASK_E64V, CMP_CND_VCC, CMP_CND_S, AND_, OR_, LSHL, ADD_U, SUB_F, MAX3, FMA_MOD, BFE, EXP, CND32_FMA, CND32_2FMA, CMP_3CND32, CMP_3CND64, CMP_3CND64V, FMA_WAITCNT, FMA_NOP, FMA_SMOV, FMA_SAVEEXEC, N_OPS };
+          FMA64, MAD64, FMA_SALU, FMA_2SALU, FMA_DEP, CNDMASK_VCCSET, CNDMASK_E64V, CMP_CND_VCC, CMP_CND_S, AND_, OR_, LSHL, ADD_U, SUB_F, MAX3, FMA_MOD, BFE, EXP, CND32_FMA, CND32_2FMA, CMP_3CND32, CMP_3CND64, CMP_3CND64V, FMA_WAITCNT, FMA_NOP, FMA_SMOV, FMA_SAVEEXEC,
+          BFI, ADD3, OR3, XAD, LSHR, PERM, ALIGNBIT, MAXU, SUBU, MED3F, FLOOR, FRACT, CVT_UB, CVT_FU, LDEXP, ADD_DPP, MUL_CLAMP, AND_SDWA, N_OPS };
 
 #define BODY32(M, extra_in...) asm volatile(R16(M) R16(M) : REGS16(a) : extra_in : "vcc", "scc", "s20", "s21", "s22", "s23")
 
@@ -127,7 +146,8 @@ __global__ __launch_bounds__(256) void k(unsigned long long *stamps, float *sink
         t1 = __builtin_amdgcn_s_memtime();
         for (int i = 0; i < 16; ++i) r += (float)a[i];
     } else if constexpr (OP == MUL_LO || OP == MUL_HI || OP == MAD_U24 || OP == XOR || OP == LSHL_ADD || OP == AND_OR || OP == MED3U ||
-                         OP == MINU || OP == CVT_U || OP == AND_ || OP == OR_ || OP == LSHL || OP == ADD_U || OP == BFE) {
+                         OP == MINU || OP == CVT_U || OP == AND_ || OP == OR_ || OP == LSHL || OP == ADD_U || OP == BFE || OP == BFI || OP == ADD3 ||
+                         OP == OR3 || OP == XAD || OP == LSHR || OP == PERM || OP == ALIGNBIT || OP == MAXU || OP == SUBU || OP == CVT_UB || OP == AND_SDWA) {
         unsigned a[16];
         for (int i = 0; i < 16; ++i) a[i] = ((unsigned)(seed * 977.0f) + 31u * i + threadIdx.x) | 1u;
         const unsigned m0 = 0xD2511F53u + threadIdx.x, m1 = 0x00FFF0F0u ^ threadIdx.x;
@@ -147,6 +167,17 @@ __global__ __launch_bounds__(256) void k(unsigned long long *stamps, float *sink
             if constexpr (OP == LSHL) BODY32(I_LSHL, "v"(m0), "v"(m1));
             if constexpr (OP == ADD_U) BODY32(I_ADD_U, "v"(m0), "v"(m1));
             if constexpr (OP == BFE) BODY32(I_BFE, "v"(m0), "v"(m1));
+            if constexpr (OP == BFI) BODY32(I_BFI, "v"(m0), "v"(m1));
+            if constexpr (OP == ADD3) BODY32(I_ADD3, "v"(m0), "v"(m1));
+            if constexpr (OP == OR3) BODY32(I_OR3, "v"(m0), "v"(m1));
+            if constexpr (OP == XAD) BODY32(I_XAD, "v"(m0), "v"(m1));
+            if constexpr (OP == LSHR) BODY32(I_LSHR, "v"(m0), "v"(m1));
+            if constexpr (OP == PERM) BODY32(I_PERM, "v"(m0), "v"(m1));
+            if constexpr (OP == ALIGNBIT) BODY32(I_ALIGNBIT, "v"(m0), "v"(m1));
+            if constexpr (OP == MAXU) BODY32(I_MAXU, "v"(m0), "v"(m1));
+            if constexpr (OP == SUBU) BODY32(I_SUBU, "v"(m0), "v"(m1));
+            if constexpr (OP == CVT_UB) BODY32(I_CVT_UB, "v"(m0), "v"(m1));
+            if constexpr (OP == AND_SDWA) BODY32(I_AND_SDWA, "v"(m0), "v"(m1));
         }
         t1 = __builtin_amdgcn_s_memtime();
         for (int i = 0; i < 16; ++i) r += (float)a[i];
@@ -197,6 +228,13 @@ __global__ __launch_bounds__(256) void k(unsigned long long *stamps, float *sink
             if constexpr (OP == FMA_SALU) BODY32(I_FMA_SALU, "v"(s), "v"(t));
             if constexpr (OP == FMA_2SALU) BODY32(I_FMA_2SALU, "v"(s), "v"(t));
             if constexpr (OP == FMA_DEP) BODY32(I_FMA_DEP, "v"(s), "v"(t));
+            if constexpr (OP == MED3F) BODY32(I_MED3F, "v"(s), "v"(t));
+            if constexpr (OP == FLOOR) BODY32(I_FLOOR, "v"(s), "v"(t));
+            if constexpr (OP == FRACT) BODY32(I_FRACT, "v"(s), "v"(t));
+            if constexpr (OP == CVT_FU) BODY32(I_CVT_FU, "v"(s), "v"(t));
+            if constexpr (OP == LDEXP) BODY32(I_LDEXP, "v"(s), "v"(t));
+            if constexpr (OP == ADD_DPP) BODY32(I_ADD_DPP, "v"(s), "v"(t));
+            if constexpr (OP == MUL_CLAMP) BODY32(I_MUL_CLAMP, "v"(s), "v"(t));
         }
         t1 = __builtin_amdgcn_s_memtime();
         for (int i = 0; i < 16; ++i) r += a[i];
@@ -308,5 +346,23 @@ int main() {
     run<FMA_SALU>("v_fma_f32 + 1 s_add_u32 (per VALU op)", n_cu, d_stamps, d_sink);
     run<FMA_2SALU>("v_fma_f32 + 2 SALU (per VALU op)", n_cu, d_stamps, d_sink);
     run<FMA_DEP>("v_fma_f32 dependent chain (latency)", n_cu, d_stamps, d_sink);
+    run<BFI>("v_bfi_b32 v,v,v,v", n_cu, d_stamps, d_sink);
+    run<ADD3>("v_add3_u32 v,v,v,v", n_cu, d_stamps, d_sink);
+    run<OR3>("v_or3_b32 v,v,v,v", n_cu, d_stamps, d_sink);
+    run<XAD>("v_xad_u32 v,v,v,v", n_cu, d_stamps, d_sink);
+    run<LSHR>("v_lshrrev_b32 v,3,v", n_cu, d_stamps, d_sink);
+    run<PERM>("v_perm_b32 v,v,v,v", n_cu, d_stamps, d_sink);
+    run<ALIGNBIT>("v_alignbit_b32 v,v,v,7", n_cu, d_stamps, d_sink);
+    run<MAXU>("v_max_u32 v,v,v", n_cu, d_stamps, d_sink);
+    run<SUBU>("v_sub_u32 v,v,v", n_cu, d_stamps, d_sink);
+    run<MED3F>("v_med3_f32 v,v,v,v", n_cu, d_stamps, d_sink);
+    run<FLOOR>("v_floor_f32 v,v", n_cu, d_stamps, d_sink);
+    run<FRACT>("v_fract_f32 v,v", n_cu, d_stamps, d_sink);
+    run<CVT_UB>("v_cvt_f32_ubyte1 v,v", n_cu, d_stamps, d_sink);
+    run<CVT_FU>("v_cvt_u32_f32 v,v", n_cu, d_stamps, d_sink);
+    run<LDEXP>("v_ldexp_f32 v,v,3", n_cu, d_stamps, d_sink);
+    run<ADD_DPP>("v_add_f32_dpp v,v,v row_shr:1", n_cu, d_stamps, d_sink);
+    run<MUL_CLAMP>("v_mul_f32_e64 v,v,v clamp", n_cu, d_stamps, d_sink);
+    run<AND_SDWA>("v_and_b32_sdwa v,v,v src0_sel:BYTE_1", n_cu, d_stamps, d_sink);
     return 0;
 }

@@ -68,7 +68,7 @@ class RtSceneDesc(C.Structure):
 
 
 # rt_scene_desc.flags
-RT_SCENE_NO_PAIR_ROWS, RT_SCENE_NO_COMPACT_ROWS, RT_SCENE_NO_LINEAR_SPLIT, RT_SCENE_NO_LDS_TOP = 1, 2, 4, 8
+RT_SCENE_NO_PAIR_ROWS, RT_SCENE_NO_COMPACT_ROWS, RT_SCENE_NO_LINEAR_SPLIT, RT_SCENE_NO_LDS_TOP, RT_SCENE_NO_BOX_ROWS = 1, 2, 4, 8, 16
 
 
 def layout_switches() -> dict:
@@ -84,6 +84,8 @@ def layout_switches() -> dict:
         flags |= RT_SCENE_NO_LINEAR_SPLIT
     if env.get("RAYTRACING_AMD_NO_LDS_TOP"):
         flags |= RT_SCENE_NO_LDS_TOP
+    if env.get("RAYTRACING_AMD_NO_BOXES"):
+        flags |= RT_SCENE_NO_BOX_ROWS
 
     def num(name):
         try:

@@ -96,7 +96,7 @@ struct rt_ctx {
     bool has_scene = false;
     DevScene S{};
     int tri_mode = 0; bool has_sph = false;
-    DevBuf tri_rows, quad_rows, slab_rows, leaf_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
+    DevBuf tri_rows, quad_rows, slab_rows, box_rows, box_face_id, box_face_rows, leaf_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
@@ -389,7 +389,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         double nl = norm(N);
         TriRow r{}; TriAux x{};
         const int m = tri_mesh[t];
-        x.obj = d->mesh_obj[m]; x.face = t - d->mesh_tri_begin[m]; x.tag = 0.0f; x.pair_row = -1;
+        x.obj = d->mesh_obj[m]; x.face = t - d->mesh_tri_begin[m]; x.tag = 0u; x.pair_row = -1;
         r.gprim = d->n_spheres + t;
         // |det| = |d.N| <= |d||N|: with |d| <= 2 (longer rays use the exact code) a triangle with
         // |N| < 4e-7 can never pass upstream's |det| >= 1e-6 cut, nor can a non-finite one.
@@ -465,7 +465,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     std::vector<TriRow> rows_live, rows_quad;
     // per parallelogram row: its first triangle, the axis its plane is perpendicular to (-1: none),
     // the plane's coordinate on that axis and |N| of the row's plane functional
-    struct PairInfo { int tri; int axis; double c0, nl; };
+    struct PairInfo { int tri; int axis; double c0, nl; V3 corner[4]; int box, code; };
     std::vector<PairInfo> pair_info;
     int n_live_tris = 0;
     {
@@ -508,7 +508,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
                 r.gprim = kQuadFlag | ((d->n_spheres + y) << kQuadIdBits) | (d->n_spheres + t);
                 taken[y] = 1;
                 ++n_live_tris;
-                aux[t].tag = (float)(d->n_spheres + t + 1); aux[y].tag = -(float)(d->n_spheres + t + 1);   // ids < 8192: exact
+                aux[t].tag = (uint32_t)(d->n_spheres + t + 1); aux[y].tag = (uint32_t)(d->n_spheres + t + 1) | kTagSecond;   // ids < 8192
                 aux[t].det_hi = aux[y].det_hi = std::max(aux[t].det_hi, aux[y].det_hi);
                 int axis = -1;
                 if (N.y == 0 && N.z == 0) axis = 0; else if (N.x == 0 && N.z == 0) axis = 1; else if (N.x == 0 && N.y == 0) axis = 2;
@@ -517,10 +517,156 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
                 if (axis >= 0 && ((axis == 0 && (r.e1x != 0 || r.e2x != 0)) || (axis == 1 && (r.e1y != 0 || r.e2y != 0)) ||
                                   (axis == 2 && (r.e1z != 0 || r.e2z != 0)))) axis = -1;
                 if (d->flags & RT_SCENE_NO_COMPACT_ROWS) axis = -1;   // switch for A/B runs and tests
-                pair_info.push_back({t, axis, c0, nl});
+                pair_info.push_back({t, axis, c0, nl, {a, b, cc, dd}, -1, -1});
                 break;
             }
             ((r.gprim & kQuadFlag) ? rows_quad : rows_live).push_back(r);
+        }
+    }
+    // ---- boxes ---------------------------------------------------------------------------------
+    // Parallelogram rows that are axis-aligned rectangles (to a tolerance: walls typed with a wobble of
+    // 1e-6 count) are grouped into axis-aligned boxes; a box with at least four of its six faces in the
+    // scene replaces those faces' rows in the first pass by one box test (see BoxRow).  Greedy: of all
+    // boxes spanned by two rectangles, the one matching most rectangles first.
+    std::vector<BoxRow> box_rows;
+    std::vector<int32_t> box_face_id;
+    std::vector<int> box_face_pair;   // [8 * box + code] -> index into pair_info, -1 = none
+    double box_slack = 0, box_tilt = 0;
+    if (!(d->flags & RT_SCENE_NO_BOX_ROWS) && !pair_info.empty()) {
+        const double tol = 1e-5 * std::max(scene_radius, 1e-30);
+        struct Rect { int k, axis; double lo[3], hi[3]; double area; };
+        std::vector<Rect> rects;
+        for (int k = 0; k < (int)pair_info.size(); ++k) {
+            const PairInfo &pi = pair_info[k];
+            Rect q; q.k = k; q.axis = -1;
+            for (int ax = 0; ax < 3; ++ax) { q.lo[ax] = INFINITY; q.hi[ax] = -INFINITY; }
+            for (const V3 &p : pi.corner) {
+                const double c[3] = {p.x, p.y, p.z};
+                for (int ax = 0; ax < 3; ++ax) { q.lo[ax] = std::min(q.lo[ax], c[ax]); q.hi[ax] = std::max(q.hi[ax], c[ax]); }
+            }
+            int thin = -1, n_thin = 0;
+            for (int ax = 0; ax < 3; ++ax) {
+                if (q.hi[ax] - q.lo[ax] <= tol) { thin = ax; ++n_thin; }
+                else if (!(q.hi[ax] - q.lo[ax] > 100.0 * tol)) n_thin = 5;   // neither flat nor clearly extended (or not finite)
+            }
+            if (n_thin != 1) continue;
+            // every corner of the bounding rectangle is taken by one corner of the parallelogram
+            const int b = thin == 0 ? 1 : 0, cc = thin == 2 ? 1 : 2;
+            int seen = 0;
+            for (const V3 &p : pi.corner) {
+                const double c[3] = {p.x, p.y, p.z};
+                const bool bl = std::fabs(c[b] - q.lo[b]) <= tol, bh = std::fabs(c[b] - q.hi[b]) <= tol;
+                const bool cl = std::fabs(c[cc] - q.lo[cc]) <= tol, ch = std::fabs(c[cc] - q.hi[cc]) <= tol;
+                if ((bl || bh) && (cl || ch)) seen |= 1 << ((bh ? 1 : 0) | (ch ? 2 : 0));
+            }
+            if (seen != 15) continue;
+            q.axis = thin;
+            q.area = (q.hi[b] - q.lo[b]) * (q.hi[cc] - q.lo[cc]);
+            rects.push_back(q);
+        }
+        if (rects.size() > 128) {   // the search below is cubic: the largest rectangles only
+            std::sort(rects.begin(), rects.end(), [](const Rect &x, const Rect &y) { return x.area > y.area; });
+            rects.resize(128);
+        }
+        struct Box { double lo[3], hi[3]; };
+        auto near_ = [&](double x, double y) { return std::fabs(x - y) <= tol; };
+        auto plane_of = [](const Rect &q) { return 0.5 * (q.lo[q.axis] + q.hi[q.axis]); };
+        // which face of `bx` rectangle q is (-1: none)
+        auto face_of = [&](const Box &bx, const Rect &q) {
+            for (int ax = 0; ax < 3; ++ax)
+                if (ax != q.axis && !(near_(q.lo[ax], bx.lo[ax]) && near_(q.hi[ax], bx.hi[ax]))) return -1;
+            if (near_(plane_of(q), bx.lo[q.axis])) return 2 * q.axis;
+            if (near_(plane_of(q), bx.hi[q.axis])) return 2 * q.axis + 1;
+            return -1;
+        };
+        std::vector<char> used(rects.size(), 0);
+        while ((int)box_rows.size() < kMaxBoxes) {
+            int best_count = 0; Box best{};
+            for (size_t i = 0; i < rects.size(); ++i) {
+                if (used[i]) continue;
+                for (size_t j = i + 1; j < rects.size(); ++j) {
+                    if (used[j]) continue;
+                    const Rect &p = rects[i], &q = rects[j];
+                    Box bx;
+                    if (p.axis == q.axis) {   // opposite faces
+                        const int a = p.axis;
+                        bool same = true;
+                        for (int ax = 0; ax < 3; ++ax) if (ax != a) same = same && near_(p.lo[ax], q.lo[ax]) && near_(p.hi[ax], q.hi[ax]);
+                        if (!same) continue;
+                        for (int ax = 0; ax < 3; ++ax) { bx.lo[ax] = p.lo[ax]; bx.hi[ax] = p.hi[ax]; }
+                        bx.lo[a] = std::min(plane_of(p), plane_of(q)); bx.hi[a] = std::max(plane_of(p), plane_of(q));
+                    } else {                  // faces that share an edge
+                        const int a1 = p.axis, a2 = q.axis, a3 = 3 - a1 - a2;
+                        if (!(near_(p.lo[a3], q.lo[a3]) && near_(p.hi[a3], q.hi[a3]))) continue;
+                        if (!(near_(plane_of(p), q.lo[a1]) || near_(plane_of(p), q.hi[a1]))) continue;
+                        if (!(near_(plane_of(q), p.lo[a2]) || near_(plane_of(q), p.hi[a2]))) continue;
+                        bx.lo[a1] = q.lo[a1]; bx.hi[a1] = q.hi[a1];
+                        bx.lo[a2] = p.lo[a2]; bx.hi[a2] = p.hi[a2];
+                        bx.lo[a3] = p.lo[a3]; bx.hi[a3] = p.hi[a3];
+                    }
+                    bool thick = true;
+                    for (int ax = 0; ax < 3; ++ax) thick = thick && (bx.hi[ax] - bx.lo[ax] > 100.0 * tol);
+                    if (!thick) continue;
+                    int faces = 0, count = 0;
+                    for (size_t m = 0; m < rects.size(); ++m) {
+                        if (used[m]) continue;
+                        const int f = face_of(bx, rects[m]);
+                        if (f >= 0 && !(faces & (1 << f))) { faces |= 1 << f; ++count; }
+                    }
+                    if (count > best_count) { best_count = count; best = bx; }
+                }
+            }
+            if (best_count < 4) break;
+            const int bi = (int)box_rows.size();
+            int face_rect[6] = {-1, -1, -1, -1, -1, -1};
+            for (size_t m = 0; m < rects.size(); ++m) {
+                if (used[m]) continue;
+                const int f = face_of(best, rects[m]);
+                if (f >= 0 && face_rect[f] < 0) { face_rect[f] = (int)m; used[m] = 1; }
+            }
+            // the ideal planes: a present face's own plane, else the extent of the others
+            float lo[3], hi[3];
+            for (int ax = 0; ax < 3; ++ax) {
+                lo[ax] = (float)(face_rect[2 * ax] >= 0 ? plane_of(rects[face_rect[2 * ax]]) : best.lo[ax]);
+                hi[ax] = (float)(face_rect[2 * ax + 1] >= 0 ? plane_of(rects[face_rect[2 * ax + 1]]) : best.hi[ax]);
+            }
+            BoxRow br{};
+            br.lox = lo[0]; br.loy = lo[1]; br.loz = lo[2]; br.hix = hi[0]; br.hiy = hi[1]; br.hiz = hi[2];
+            br.base = (uint32_t)(n_gprim + 1 + 8 * bi);
+            for (int f = 0; f < 8; ++f) { box_face_id.push_back(-1); box_face_pair.push_back(-1); }
+            for (int f = 0; f < 6; ++f) {
+                if (face_rect[f] < 0) continue;
+                const Rect &q = rects[face_rect[f]];
+                PairInfo &pi = pair_info[q.k];
+                // how far the true face is from the ideal one, per coordinate
+                for (const V3 &p : pi.corner) {
+                    const double c[3] = {p.x, p.y, p.z};
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const double dl = std::fabs(c[ax] - (double)lo[ax]), dh = std::fabs(c[ax] - (double)hi[ax]);
+                        const double dev = ax == q.axis ? ((f & 1) ? dh : dl) : std::min(dl, dh);
+                        box_slack = std::max(box_slack, dev);
+                    }
+                }
+                {   // how far the true face's normal leans away from its axis (sine of the angle)
+                    const V3 N = cross(sub(pi.corner[1], pi.corner[0]), sub(pi.corner[2], pi.corner[0]));
+                    const double n[3] = {N.x, N.y, N.z};
+                    const int o1 = (q.axis + 1) % 3, o2 = (q.axis + 2) % 3;
+                    box_tilt = std::max(box_tilt, std::sqrt(n[o1] * n[o1] + n[o2] * n[o2]) / norm(N));
+                }
+                br.present |= 1u << f;
+                pi.box = bi; pi.code = f;
+                const int id1 = d->n_spheres + pi.tri;
+                box_face_id[8 * bi + f] = id1;
+                box_face_pair[8 * bi + f] = q.k;
+            }
+            box_rows.push_back(br);
+        }
+        // the origin tags of the faces' triangles (both triangles of a row carry the row's box face)
+        for (int t = 0; t < d->n_tris; ++t) {
+            const uint32_t id1p = aux[t].tag & kTagIdMask;
+            if (id1p == 0) continue;
+            for (size_t f = 0; f < box_face_id.size(); ++f)
+                if (box_face_id[f] >= 0 && (uint32_t)(box_face_id[f] + 1) == id1p) aux[t].tag |= (uint32_t)(f + 1) << kTagBoxShift;
         }
     }
     // Parallelogram rows in general position first, then those in axis-perpendicular planes (by axis);
@@ -530,9 +676,10 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     uint32_t slab_counts = 0;
     {
         int per_axis[3] = {0, 0, 0};
-        for (auto &pi : pair_info) if (pi.axis >= 0 && ++per_axis[pi.axis] > 1022) { pi.axis = -1; }
+        // order: general position, box faces (tested through their boxes), compact rows by axis
+        for (auto &pi : pair_info) { if (pi.box >= 0) pi.axis = -2; if (pi.axis >= 0 && ++per_axis[pi.axis] > 1022) pi.axis = -1; }
         std::vector<int> order;
-        for (int pass = -1; pass < 3; ++pass)
+        for (int pass : {-1, -2, 0, 1, 2})
             for (int k = 0; k < (int)pair_info.size(); ++k) if (pair_info[k].axis == pass) order.push_back(k);
         std::vector<TriRow> sorted(rows_quad.size());
         int counts[3] = {0, 0, 0};
@@ -548,7 +695,8 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             const TriRow &q = rows_quad[order[k]];
             sorted[k] = q;
             aux[pi.tri].pair_row = k;
-            if (pi.axis < 0) { ++n_quad_general; continue; }
+            if (pi.axis == -1) { ++n_quad_general; continue; }
+            if (pi.axis == -2) continue;
             ++counts[pi.axis];
             SlabRow sr{};
             sr.c0 = (float)pi.c0;
@@ -570,6 +718,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         }
         close_axis(last_axis);
         rows_quad.swap(sorted);
+        // (the sort above moved the rows: pair_info[k] now sits at rows_quad[aux[pair_info[k].tri].pair_row])
         slab_counts = (uint32_t)counts[0] | ((uint32_t)counts[1] << 10) | ((uint32_t)counts[2] << 20);
         if (!rows_slab.empty()) rows_slab.push_back(dead_slab);   // the row the loops may read ahead into
     }
@@ -610,6 +759,23 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         while (tab->size() % 2) tab->push_back(dead);
         for (int k = 0; k < 2; ++k) tab->push_back(dead);
     }
+    // box tables: the faces' parallelogram rows by 8 * box + code (dead where there is no face), and one spare box row to read ahead into
+    std::vector<TriRow> box_face_rows(box_face_id.size());
+    for (size_t f = 0; f < box_face_rows.size(); ++f) {
+        TriRow dead{}; dead.kn = 1; dead.k1 = dead.k2 = -1; dead.det_lo = INFINITY; dead.gprim = -2;
+        box_face_rows[f] = box_face_pair[f] >= 0 ? rows_quad[aux[pair_info[box_face_pair[f]].tri].pair_row] : dead;
+    }
+    const int n_boxes = (int)box_rows.size();
+    if (n_boxes > 0) {
+        // the box loop takes two per trip: an odd count is padded with a box far outside every scene the
+        // float32 code handles (it has no faces; its ids lie above the real boxes'), plus one row to read ahead into
+        BoxRow far_box{};
+        far_box.lox = far_box.loy = far_box.loz = 3.0e18f; far_box.hix = far_box.hiy = far_box.hiz = 3.1e18f;
+        far_box.present = 0; far_box.base = (uint32_t)(n_gprim + 1 + 8 * n_boxes);
+        if (n_boxes % 2) box_rows.push_back(far_box);
+        box_rows.push_back(far_box);
+    }
+    HIP_TRY(c, c->box_rows.upload(box_rows)); HIP_TRY(c, c->box_face_id.upload(box_face_id)); HIP_TRY(c, c->box_face_rows.upload(box_face_rows));
     HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->slab_rows.upload(rows_slab)); HIP_TRY(c, c->leaf_rows.upload(rows_leaf)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
     HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
     HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));
@@ -646,6 +812,8 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.tri_rows = c->tri_rows.as<TriRow>(); S.n_tri_rows = n_live; S.n_tri_rows_padded = any_tri_rows ? (int)rows_live.size() - 2 : 0;
     S.quad_rows = c->quad_rows.as<TriRow>(); S.n_quad_rows_padded = any_quad_rows ? (int)rows_quad.size() - 2 : 0;
     S.slab_rows = c->slab_rows.as<SlabRow>(); S.n_quad_general = n_quad_general; S.slab_counts = slab_counts;
+    S.box_rows = c->box_rows.as<BoxRow>(); S.box_face_id = c->box_face_id.as<int32_t>(); S.box_face_rows = c->box_face_rows.as<TriRow>();
+    S.n_boxes = n_boxes; S.box_slack = up(1.01 * box_slack); S.box_tilt = up(1.01 * box_tilt + 1e-7);
     S.sph_rows = c->sph_rows.as<SphRow>(); S.n_sph_rows = (int)sph_small.size();
     S.big_sph = c->big_sph.as<int32_t>(); S.n_big_sph = (int)big.size();
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();
@@ -670,7 +838,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.n_prims = (int32_t)n_gprim;
     S.scene_radius = up(scene_radius * 1.000001);
     int bits = 5;
-    while ((1ll << bits) < n_gprim && bits < 23) ++bits;   // only the linear walk's 32-bit keys use it
+    while ((1ll << bits) < n_gprim + 1 + 8 * (n_boxes + 1) && bits < 23) ++bits;   // only the linear walk's 32-bit keys use it (box faces have ids too)
     S.key_mask = (1u << bits) - 1u;
     S.dof_on = !(d->cam_dof_dist == 0 || d->cam_dof_strength == 0);   // camera.py:41
     S.sky = has_sky ? c->sky.as<uint32_t>() : nullptr; S.sky_w = has_sky ? d->sky_w : 0; S.sky_h = has_sky ? d->sky_h : 0;
@@ -1165,6 +1333,18 @@ extern "C" int rt_debug_uniforms(rt_ctx *c, uint32_t pixel, uint32_t sample, uin
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(out_host, b.p, (size_t)n_segments * 5 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// How the current scene's triangles were laid out (tests and tuning).
+extern "C" int rt_debug_scene_layout(rt_ctx *c, int32_t *out, int32_t n_out, float *box_slack) {
+    if (!c || !out || n_out < 8) return fail(c, RT_ERR_INVALID_ARG, "rt_debug_scene_layout: bad arguments");
+    if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "rt_debug_scene_layout: no scene");
+    const DevScene &S = c->S;
+    out[0] = S.n_quad_rows_padded; out[1] = S.n_quad_general;
+    out[2] = (int32_t)(S.slab_counts & 1023u); out[3] = (int32_t)((S.slab_counts >> 10) & 1023u); out[4] = (int32_t)(S.slab_counts >> 20);
+    out[5] = S.n_tri_rows_padded; out[6] = S.n_boxes; out[7] = S.n_bvh_nodes;
+    if (box_slack) *box_slack = S.box_slack;
     return RT_OK;
 }
 

@@ -129,20 +129,22 @@ struct Ray {
     float c4, c7;          // triangle bounds: q = c7 |t| + c4 with c4 = 4u S, c7 = 7u |d|, S = |o| + scene_radius
     float band0;           // crude per-ray discriminant bound for the in-loop sphere test
     int32_t origin;        // global id of the primitive the ray starts on, -1 = none
-    // The same fact in the form the compact parallelogram rows test it (TriAux::tag of the origin):
-    float own_idf;         // |tag| = (float)(id + 1) of the first triangle of the origin's row, 0 = the origin heads no such row
+    // The same fact in the forms the compact rows and the box rows test it (from TriAux::tag of the origin):
+    float own_idf;         // (float)(id + 1) of the first triangle of the origin's parallelogram row, 0 = the origin is in no such row
     float own_sign;        // +1: the origin is that first triangle (the side u > 0), -1: the second
+    uint32_t own_box;      // 1 + 8 * box + code of the box face the origin's row is, 0 = none
+    float own_ratio;       // Hit::own_ratio of the hit this ray leaves from (+inf: unknown)
 };
 
 // TriAux::tag of the primitive a ray starts on (0 for none, a sphere, or a triangle in no parallelogram row).
-RT_DEV float origin_tag(SceneRef S, int32_t origin) {
-    return (origin >= S.n_spheres && origin < S.n_prims) ? S.tri_aux[origin - S.n_spheres].tag : 0.0f;
+RT_DEV uint32_t origin_tag(SceneRef S, int32_t origin) {
+    return (origin >= S.n_spheres && origin < S.n_prims) ? S.tri_aux[origin - S.n_spheres].tag : 0u;
 }
 
 // `rounded` = the ray is the float32 rounding of a double-precision ray the exact code will use
 // (camera rays): every bound then also covers u per component of o and d.
 RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy, float dz, int32_t origin,
-                    bool rounded, float tag) {
+                    bool rounded, uint32_t tag, float own_ratio = kInf) {
     Ray r;
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.a = fma_(dz, dz, fma_(dy, dy, dx * dx));
@@ -155,16 +157,19 @@ RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy
     r.c7 = 7.0f * k * r.dlen;
     r.band0 = 72.0f * kU * r.a * Sr * Sr;
     r.origin = origin;
-    r.own_idf = abs_(tag);
-    r.own_sign = tag < 0.0f ? -1.0f : 1.0f;
+    r.own_idf = (float)(tag & kTagIdMask);
+    r.own_sign = u2f(0x3F800000u | (tag & kTagSecond));
+    r.own_box = (tag >> kTagBoxShift) & kTagBoxMask;
+    r.own_ratio = own_ratio;
     return r;
 }
 
 RT_DEV bool ray_needs_exact(const Ray &r) {
-    // the filter takes the ray when 1/4 <= d.d <= 4, no component of d is zero and |o| < 1e18: the
-    // smallest of three margins is positive (one compare instead of six and their mask arithmetic;
-    // a NaN or infinity anywhere fails the compare and sends the ray to the exact code)
-    const float m = min_(min_(abs_(r.dx), abs_(r.dy)), abs_(r.dz));
+    // the filter takes the ray when 1/4 <= d.d <= 4, every component of d is above 1e-18 in size (so
+    // that 1 / d_a and o_a / d_a are finite numbers) and |o| < 1e18: the smallest of three margins is
+    // positive (one compare instead of six and their mask arithmetic; a NaN or infinity anywhere
+    // fails the compare and sends the ray to the exact code)
+    const float m = min_(min_(abs_(r.dx), abs_(r.dy)), abs_(r.dz)) - 1e-18f;
     const float in_range = 1.875f - abs_(r.a - 2.125f);   // >= 0 exactly when 1/4 <= d.d <= 4
     const float q = min_(min_(m, in_range + 1e-30f), 1e18f - r.o2);
     // (min drops a NaN operand: 0 * (d.d + |o|) puts a NaN or an infinity back into the compare)
@@ -485,6 +490,156 @@ RT_DEV void slab_loop(const SlabRow *rows, int begin, int n, const Ray &r, Sink 
     } while (n > 0);
 }
 
+// Per-lane row load (hierarchy leaves: every lane is somewhere else in the table).
+RT_DEV TriRow load_tri_row_lane(const TriRow *rows, int i) {
+    const f4 *q = (const f4 *)(rows + i);
+    f4 a = q[0], b = q[1], c = q[2], d = q[3];
+    TriRow T;
+    T.nx = a.x; T.ny = a.y; T.nz = a.z; T.kn = a.w;
+    T.e1x = b.x; T.e1y = b.y; T.e1z = b.z; T.k1 = b.w;
+    T.e2x = c.x; T.e2y = c.y; T.e2z = c.z; T.k2 = c.w;
+    T.cb = d.x; T.ct = d.y; T.det_lo = d.z;
+    const float id_bits = d.w;
+    T.gprim = (int32_t)f2u(id_bits);
+    return T;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Box rows (see BoxRow): one slab test per box instead of one compact row per face.
+//
+// Per axis a the ray crosses the box's two planes at v = plane / d_a - o_a / d_a; the smaller is the
+// axis' entry value, the larger its exit value; the ray is inside the box for
+// tn = max(entries) <= t <= tf = min(exits).  The box's boundary is crossed at tn (through the face
+// whose plane gave tn) and at tf, nowhere else: those two faces are the only ones the ray can hit.
+// Which plane gave tn is carried in the value itself: each v has its face code written over its low
+// three mantissa bits before the minima and maxima are taken (8 ulp, inside the band below).
+//
+// Error band.  A computed v is within E(t) = c7i_a |t| + c4i_a of the exact crossing (the compact
+// rows' model); a point of a TRUE face lies within box_slack, per coordinate, of the ideal face.  With
+//     band(t) = c7m |t| + c4m,   c7m = (1.05 c7 + 32 u) max_a |1/d_a|,   c4m = 1.05 (c4 + box_slack) max_a |1/d_a|
+// the following holds for a ray that hits true face f at depth t* > 0 (f's plane being, say, the
+// entry plane of its axis): v_f >= t* - band, every other entry value <= t* + band, every exit
+// value >= t* - band.  Hence v_f is the largest entry value or within 2 band of it; tf - tn >=
+// -2 band; tn + band >= 0; tn - band <= t* + ... so: the entry face is nominated with lower depth
+// bound tn - 3.5 band when min(tf - tn + band(tn) + band(tf), tn + band(tn)) >= 0, under the id of
+// the face whose plane gave tn - or, when the second largest entry value is within 2.5 band of tn
+// (the ray enters near an edge of the box), under the reserved id that opens every candidate.  The
+// exit face likewise.  A nominated face that the scene does not hold, or that is the ray's own
+// origin, is dropped - but only when the nomination is unambiguous.  The origin's own face row is
+// tested on its own, from its parallelogram row, by the caller: that test applies the origin rule
+// at the ray's actual crossing point.
+// ---------------------------------------------------------------------------------------------
+struct BoxRay {
+    float ix, iy, iz, nx, ny, nz;   // 1 / d_a and -o_a / d_a
+    float c7m, c4m;
+    float dmin;                     // smallest |d_a|
+    uint32_t own_id;                // candidate id of the box face the ray starts on (amb_id: none)
+    uint32_t amb_id;                // the reserved id (= n_prims)
+};
+
+RT_DEV BoxRay box_ray(SceneRef S, const Ray &r) {
+    BoxRay a;
+    a.ix = rcp_(r.dx); a.iy = rcp_(r.dy); a.iz = rcp_(r.dz);
+    a.nx = -(r.ox * a.ix); a.ny = -(r.oy * a.iy); a.nz = -(r.oz * a.iz);
+    const float imax = max3_(abs_(a.ix), abs_(a.iy), abs_(a.iz));
+    a.c7m = fma_(1.05f, r.c7, 32.0f * kU) * imax;
+    a.c4m = 1.05f * (r.c4 + S.box_slack) * imax;
+    a.dmin = min3_(abs_(r.dx), abs_(r.dy), abs_(r.dz));
+    a.amb_id = (uint32_t)S.n_prims;
+    a.own_id = a.amb_id + r.own_box;
+    return a;
+}
+
+RT_DEV BoxRow load_box_row_uniform(const BoxRow *rows, int i) {
+    const_f4_ptr q = as_const_f4(rows) + 2 * (size_t)i;
+    const f4 a = q[0], b = q[1];
+    BoxRow B;
+    B.lox = a.x; B.loy = a.y; B.loz = a.z; B.hix = a.w;
+    B.hiy = b.x; B.hiz = b.y;
+    const float pb = b.z, bb = b.w;
+    B.present = f2u(pb); B.base = f2u(bb);
+    return B;
+}
+
+RT_DEV float with_code(float v, uint32_t code) { return u2f((f2u(v) & ~7u) | code); }
+RT_DEV float med3_(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+// Minimum / maximum of values that went through integer bit operations: written as the instruction
+// itself, because the compiler, which cannot know that such a value is no signalling NaN, puts a
+// canonicalising v_max_f32 x, x, x in front of every use in an ordinary minimum (the values here are
+// finite: see ray_needs_exact).
+RT_DEV float min_bits(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float max_bits(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+template <class Sink>
+RT_DEV void box_row_test(const BoxRow &B, const BoxRay &a, Sink &sink) {
+    const float xl = with_code(fma_(B.lox, a.ix, a.nx), 0u), xh = with_code(fma_(B.hix, a.ix, a.nx), 1u);
+    const float yl = with_code(fma_(B.loy, a.iy, a.ny), 2u), yh = with_code(fma_(B.hiy, a.iy, a.ny), 3u);
+    const float zl = with_code(fma_(B.loz, a.iz, a.nz), 4u), zh = with_code(fma_(B.hiz, a.iz, a.nz), 5u);
+    const float nx = min_bits(xl, xh), fx = max_bits(xl, xh);
+    const float ny = min_bits(yl, yh), fy = max_bits(yl, yh);
+    const float nz = min_bits(zl, zh), fz = max_bits(zl, zh);
+    const float tn = max3_(nx, ny, nz), tm = med3_(nx, ny, nz);
+    const float tf = min3_(fx, fy, fz), tq = med3_(fx, fy, fz);
+    const float bn = fma_(a.c7m, abs_(tn), a.c4m), bf = fma_(a.c7m, abs_(tf), a.c4m);
+    const float gap = (tf - tn) + (bn + bf);
+    {   // entry
+        const uint32_t code = f2u(tn) & 7u, id = B.base + code;
+        const bool amb = !(tn - tm > 2.5f * bn);
+        const bool ok = ((B.present >> code) & 1u) != 0u && id != a.own_id;
+        const float x = min_(gap, tn + bn);
+        const float y = x * (-kInf);                 // x < 0 -> +inf (not a candidate); x >= 0 -> -inf / NaN
+        const float tl = max3_(fma_(-3.5f, bn, tn), 0.0f, y);
+        sink((amb || ok) ? tl : kInf, (int32_t)(amb ? a.amb_id : id));
+    }
+    {   // exit
+        const uint32_t code = f2u(tf) & 7u, id = B.base + code;
+        const bool amb = !(tq - tf > 2.5f * bf);
+        const bool ok = ((B.present >> code) & 1u) != 0u && id != a.own_id;
+        const float x = min_(gap, tf + bf);
+        const float y = x * (-kInf);
+        const float tl = max3_(fma_(-3.5f, bf, tf), 0.0f, y);
+        sink((amb || ok) ? tl : kInf, (int32_t)(amb ? a.amb_id : id));
+    }
+}
+
+// All boxes, then the ray's own box face from its parallelogram row (per-lane load: every lane starts somewhere else).
+template <class Sink>
+RT_DEV void box_loop(SceneRef S, const Ray &r, Sink &sink) {
+    const int n = S.n_boxes;
+    if (n <= 0) return;
+    const BoxRay a = box_ray(S, r);
+    const BoxRow *rows = S.box_rows;
+    // two boxes per trip from two sets of scalar registers that take turns, as in slab_loop (the host
+    // pads the table to an even count with a box no ray of the filter's range comes near, plus one to read ahead into)
+    const BoxRow *p = rows;
+    BoxRow A = load_box_row_uniform(p, 0);
+    int left = (n + 1) & ~1;
+    do {
+        const BoxRow *pb = p + 1;
+        asm volatile("" : "+s"(pb) : "s"(A.lox));
+        const BoxRow B = load_box_row_uniform(pb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        box_row_test(A, a, sink);
+        __builtin_amdgcn_sched_barrier(0);
+        p += 2;
+        asm volatile("" : "+s"(p) : "s"(B.lox));
+        A = load_box_row_uniform(p, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        box_row_test(B, a, sink);
+        left -= 2;
+    } while (left > 0);
+    // The origin's own face.  Its plane N (unit) is within box_tilt of its axis a: |N.d| >= 0.99 |d_a| -
+    // box_tilt |d| =: den for box_tilt <= 0.1, so by Hit::own_ratio the row is out when
+    // own_ratio (1 + |d| / den) < 1 (false for den <= 0, an infinite ratio or a NaN: then the row is tested).
+    const float den = fma_(-S.box_tilt, r.dlen, 0.99f * a.dmin);
+    const bool own_out = 1.05f * r.own_ratio * (den + r.dlen) < den;
+    if (r.own_box != 0u && !own_out) {
+        const uint32_t k = umin_(r.own_box - 1u, (uint32_t)(8 * n - 1));
+        const TriRow T = load_tri_row_lane(S.box_face_rows, (int)k);
+        pair_candidate(row_eval(T, r), T.gprim, r, sink);
+    }
+}
+
 // Brute-force loops over the two linear tables (parallelogram rows, then triangle rows), two rows
 // per trip.  Each table is padded with dead rows to an even count plus two, so the loops need no
 // tail and may read one trip ahead: a row's scalar load is issued a full test (~40 vector
@@ -504,6 +659,7 @@ RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
             }
         }
         if (!Sink::kPerTriangle) PROF(kProfQuadRows);
+        if (!Sink::kPerTriangle) box_loop(S, r, sink);
         if (!Sink::kPerTriangle && S.slab_counts != 0) {
             const int nx = (int)(S.slab_counts & 1023u), ny = (int)((S.slab_counts >> 10) & 1023u), nz = (int)(S.slab_counts >> 20);
             slab_loop<0>(S.slab_rows, 0, nx, r, sink);
@@ -522,20 +678,6 @@ RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
             cur = next;
         }
     }
-}
-
-// Per-lane row load (hierarchy leaves: every lane is somewhere else in the table).
-RT_DEV TriRow load_tri_row_lane(const TriRow *rows, int i) {
-    const f4 *q = (const f4 *)(rows + i);
-    f4 a = q[0], b = q[1], c = q[2], d = q[3];
-    TriRow T;
-    T.nx = a.x; T.ny = a.y; T.nz = a.z; T.kn = a.w;
-    T.e1x = b.x; T.e1y = b.y; T.e1z = b.z; T.k1 = b.w;
-    T.e2x = c.x; T.e2y = c.y; T.e2z = c.z; T.k2 = c.w;
-    T.cb = d.x; T.ct = d.y; T.det_lo = d.z;
-    const float id_bits = d.w;
-    T.gprim = (int32_t)f2u(id_bits);
-    return T;
 }
 
 // Stackless walk of the threaded hierarchy (node layout: rt_bvh_node).  Conservative slab test: the
@@ -626,7 +768,7 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
 
 // Winner re-evaluation.  status: 0 accept float32 result, 1 identity certain but imprecise,
 // 2 undecided (ask the exact code about this primitive).
-struct Verdict { int status; float t, thi; int32_t ti; bool open; };
+struct Verdict { int status; float t, thi; int32_t ti; bool open; float ratio; };   // ratio: see Hit::own_ratio
 
 // `ti` = triangle index the first pass named.  With PAIRS (first passes that report a parallelogram
 // row as one candidate) a triangle that heads such a row stands for the pair: the row itself is
@@ -650,6 +792,16 @@ RT_DEV Verdict judge_tri(SceneRef S, int32_t ti, const Ray &r, float rel_accept,
     }
     const bool certain = !e.dead && !v.open && (m - e.bb >= 0.0f) && (e.tlo > kTCertain) && (e.nd_abs >= X.det_hi);
     v.t = e.t; v.thi = e.thi;
+    // How far, at most, the float32 hit position lies from the true crossing point, over how far, at
+    // least, that point lies inside the hit TRIANGLE (all three of its edges, the pair's diagonal
+    // included).  Barycentric margins turn into distances through their gradients: |grad u| = |e1|,
+    // |grad v| = |e2|, |grad (u + v)| <= |e1| + |e2| <= 0.4494 cb / ct by the definitions of cb and ct.
+    {
+        const float mu = (pair ? min_(m, abs_(e.u)) : m) - e.bb;
+        const float room = 2.2f * mu * T.ct;                     // times 1 / cb: folded into the quotient
+        const float off = fma_(bt, r.dlen, r.c4) * T.cb;
+        v.ratio = mu > 0.0f ? off * rcp_(room) : kInf;
+    }
     v.status = !certain ? 2 : ((bt <= max_(rel_accept * e.t, abs_accept)) ? 0 : 1);
     return v;
 }
@@ -793,7 +945,13 @@ RT_DEV void search_few_spheres(SceneRef S, const Ray &r, Sink &sink, SpherePre &
 struct Hit {
     int32_t obj, prim, gprim;   // obj < 0: miss
     float t, nx, ny, nz, px, py, pz;
-    float tag;                  // TriAux::tag of the hit triangle (0 for a sphere): what the next ray's origin test needs
+    uint32_t tag;               // TriAux::tag of the hit triangle (0 for a sphere): what the next ray's origin test needs
+    // Upper bound on (distance of the float32 hit position from the true crossing point) / (distance of
+    // that point from the nearest edge of the hit triangle); +inf when unknown (the double-precision
+    // code produced the hit).  A ray leaving from here crosses the plane of the triangle it starts on
+    // within own_ratio * (1 + |d| / |N.d|) of that distance, N the plane's unit normal: when that is
+    // below 1 the crossing point is inside the origin triangle itself, and the row is out by the origin rule.
+    float own_ratio;
     int32_t how;                // 0 float32 filter alone, 1 winner re-evaluated in double, 2 contenders / scene settled in double
     bool refined;               // the winning primitive was re-evaluated in double precision on the way
     uint32_t bvh_nodes, bvh_tris;   // boxes and triangles this query tested in the hierarchy (0 without one)
@@ -890,21 +1048,34 @@ RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename Fi
 template <int TRI, bool HAS_SPH, bool STRICT>
 RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
                       BvhCounters bc, ExactHit *e64, const SpherePre *pre = nullptr) {
-    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0; h.tag = 0.0f;
+    Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0; h.tag = 0u; h.own_ratio = kInf;
     h.refined = false; h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
     const int route = ray_route<TRI>(r);
     int32_t gprim = -1; int root = 0; float t = kInf;
     int status = 0; float thi = kInf, second_lo = kInf; bool has_second = false;
     bool pair_open = false;   // the winner is a parallelogram row hit within the error band of its diagonal
+    bool box_open = false;    // the winner is a box face, which one is within the error band (see box_row_test)
+    bool nominee = false;     // the winner was nominated by a box test: if it turns out not to be hit, every candidate is open
     // absolute depth tolerance of the render kernel (see kAbsAcceptRender); none for the closest-hit entry
     const float abs_accept = STRICT ? 0.0f : kAbsAcceptRender * (r.o2 + S.scene_radius);
     if (route == kRouteFilter && first.any()) {
-        // (clamped: a corrupted key must never turn into an out-of-bounds table index - a wrong answer
-        // shows up in the parity tests, a wild read takes the GPU down)
-        gprim = (int32_t)umin_((uint32_t)first.best_id(), (uint32_t)(S.n_prims - 1));
+        uint32_t best = (uint32_t)first.best_id();
         second_lo = first.second_lo();
         has_second = first.has_second();
-        if (gprim < S.n_spheres) {
+        if (TRI != kTriNone && best >= (uint32_t)S.n_prims) {
+            // a box face: ids above the primitives' (the table index is clamped like every index made from a key)
+            int32_t face = -1;
+            if (best > (uint32_t)S.n_prims && S.n_boxes > 0)
+                face = S.box_face_id[umin_(best - (uint32_t)S.n_prims - 1u, (uint32_t)(8 * S.n_boxes - 1))];
+            if (face < 0) box_open = true;
+            else { best = (uint32_t)face; nominee = true; }
+        }
+        // (clamped: a corrupted key must never turn into an out-of-bounds table index - a wrong answer
+        // shows up in the parity tests, a wild read takes the GPU down)
+        gprim = (int32_t)umin_(best, (uint32_t)(S.n_prims - 1));
+        if (box_open) {
+            gprim = -1;
+        } else if (gprim < S.n_spheres) {
             if (HAS_SPH && S.n_big_sph > 0 && S.sph_by_id[gprim].qs != 0.0f) {
                 // a huge sphere: its depth is exact already (double precision, as in the search loop);
                 // position and normal follow in float32 like any other hit's (|pos - c| / r is good
@@ -921,11 +1092,11 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         } else {
             const Verdict v = judge_tri<!FirstPass<TRI>::type::kPerTriangle>(S, gprim - S.n_spheres, r,
                                                                              STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
-            status = v.status; t = v.t; thi = v.thi; gprim = S.n_spheres + v.ti; pair_open = v.open;
+            status = v.status; t = v.t; thi = v.thi; gprim = S.n_spheres + v.ti; pair_open = v.open; h.own_ratio = v.ratio;
         }
     }
     PROF(kProfJudge);
-    const bool settle = route != kRouteFilter || (gprim >= 0 && (status != 0 || (has_second && !(second_lo > thi))));
+    const bool settle = route != kRouteFilter || box_open || (gprim >= 0 && (status != 0 || (has_second && !(second_lo > thi))));
     ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
     if (settle) {
         const Ray64 x64 = ray64(r, rr);
@@ -933,8 +1104,8 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         const bool scan = route == kRouteScan;
         bool second = route == kRouteOpen; float limit = kInf;
         int32_t skip = gprim;
-        if (route == kRouteFilter && pair_open) {
-            // either triangle of the pair, or a contender: the second pass evaluates them all
+        if (route == kRouteFilter && (pair_open || box_open)) {
+            // either triangle of the pair (either face of the box), or a contender: the second pass evaluates them all
             second = true; limit = kInf; gprim = -1; skip = -1;
         } else if (route == kRouteFilter) {
             if (status == 1 && gprim >= S.n_spheres) {
@@ -951,7 +1122,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
             }
             if (status == 2 && !e.hit) {
                 // the winner was not a hit after all: every other candidate is open
-                second = has_second; limit = kInf; gprim = -1;
+                second = has_second || nominee; limit = kInf; gprim = -1;
             } else if (has_second && !(second_lo > thi)) {
                 // someone else may be in front, or tie: the contenders are settled in double precision
                 second = true; limit = thi;
@@ -988,6 +1159,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         h.obj = A.obj; h.prim = A.face; h.tag = A.tag;
     }
     if (e.hit) {
+        h.own_ratio = kInf;
         if (h.how == 0) h.how = 1;
         h.t = (float)e.t; h.nx = (float)e.n.x; h.ny = (float)e.n.y; h.nz = (float)e.n.z;
         h.px = (float)e.pos.x; h.py = (float)e.pos.y; h.pz = (float)e.pos.z;

@@ -217,7 +217,8 @@ struct Path {
     uint32_t key0, key1;            // Philox key of this (pixel, sample)
     int32_t depth;                  // closest-hit queries done so far
     int32_t origin;                 // primitive the current ray starts on, -1 = camera
-    float tag;                      // that primitive's TriAux::tag (0: none)
+    uint32_t tag;                   // that primitive's TriAux::tag (0: none)
+    float own_ratio;                // Hit::own_ratio of the hit the current ray leaves from
     bool inside;                    // Ray.inside (ray.py:10), toggled by refraction
     uint32_t pixel;                 // x * H + y: Philox key and row of the camera-ray table
 };
@@ -227,7 +228,7 @@ RT_DEV void path_begin(SceneRef S, const float *ray_dir, const float *ray_res, P
     p.key0 = pixel ^ seed_lo; p.key1 = sample ^ seed_hi;
     camera_ray(S, ray_dir, ray_res, pixel, p.key0, p.key1, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz);
     p.pixel = pixel;
-    p.tr = p.tg = p.tb = 1.0f; p.depth = 0; p.inside = false; p.origin = -1; p.tag = 0.0f;
+    p.tr = p.tg = p.tb = 1.0f; p.depth = 0; p.inside = false; p.origin = -1; p.tag = 0u; p.own_ratio = kInf;
 }
 
 
@@ -256,7 +257,7 @@ RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float
     const Draws u = segment_draws(p.key0, p.key1, (uint32_t)p.depth + 1u);
     PROF(kProfDraws);
     bool alive = shade_bounce(m, h, u, p.dx, p.dy, p.dz, p.inside, p.tr, p.tg, p.tb, er, eg, eb);
-    p.ox = h.px; p.oy = h.py; p.oz = h.pz; p.origin = h.gprim; p.tag = h.tag;
+    p.ox = h.px; p.oy = h.py; p.oz = h.pz; p.origin = h.gprim; p.tag = h.tag; p.own_ratio = h.own_ratio;
     p.depth++;
     if (alive && p.depth > max_bounces) { alive = false; er = eg = eb = 0.0f; }   // renderer.py:29-30
     return alive;
@@ -266,7 +267,7 @@ RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float
 template <int TRI, bool HAS_SPH, bool STRICT = false>
 RT_DEV bool path_step(SceneRef S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h,
                       uint32_t &sky_count) {
-    Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag);
+    Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio);
     PROF(kProfRaySetup);
     h = closest_hit<TRI, HAS_SPH, STRICT>(S, ray, nullptr, path_residue(S, ray_res, p));
     const bool alive = path_shade(S, p, max_bounces, h, er, eg, eb, sky_count);
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
     float ar = 0, ag = 0, ab = 0;
     Path p;
     p.ox = p.oy = p.oz = 0; p.dx = p.dy = 0; p.dz = 1; p.tr = p.tg = p.tb = 1; p.key0 = p.key1 = 0;
-    p.depth = 0; p.origin = -1; p.tag = 0.0f; p.inside = false; p.pixel = 0;
+    p.depth = 0; p.origin = -1; p.tag = 0u; p.own_ratio = kInf; p.inside = false; p.pixel = 0;
     // Statistics are kept per WAVE in scalar registers (lane counts of ballots taken where the wave
     // is converged), not per lane: six vector registers less for the whole life of the kernel.
     uint32_t w_exact = 0, w_refine = 0;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
             bool alive = true;
             if (TRI == kTriBvh) {
                 // resumable query: begin it if none is open, walk one slice, finish it when the walk is through
-                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag);
+                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio);
                 const RayResidue rr = path_residue(S, A.ray_res, p);
                 if (!walking) {
                     walking = true;
@@ -572,13 +573,13 @@ __global__ __launch_bounds__(256) void k_raytrace(const DevScene S_arg, const Ra
         p.key0 = p.pixel ^ A.seed_lo; p.key1 = A.sample ^ A.seed_hi;
         p.ox = (float)A.org[3 * i]; p.oy = (float)A.org[3 * i + 1]; p.oz = (float)A.org[3 * i + 2];
         p.dx = (float)A.dir[3 * i]; p.dy = (float)A.dir[3 * i + 1]; p.dz = (float)A.dir[3 * i + 2];
-        p.tr = p.tg = p.tb = 1.0f; p.depth = A.first_depth; p.origin = -1; p.tag = 0.0f;
+        p.tr = p.tg = p.tb = 1.0f; p.depth = A.first_depth; p.origin = -1; p.tag = 0u; p.own_ratio = kInf;
         p.inside = A.inside ? A.inside[i] != 0 : false;
         float er = 0, eg = 0, eb = 0;
         paths = 1;
         if (p.depth <= A.max_bounces) {   // renderer.py:29-30
             for (;;) {
-                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, false, p.tag);
+                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, false, p.tag, p.own_ratio);
                 const Hit h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, no_residue());
                 rays++;
                 if (h.obj < 0) sky++; else shaded++;

@@ -48,14 +48,32 @@ struct SlabRow {
     int32_t gprim;      // id word of the parallelogram row (see kQuadFlag)
 };
 
+// An axis-aligned BOX at least four of whose faces are parallelogram rows of the scene (a room's
+// walls, a lamp housing): all its faces are tested at once with one slab test - entry and exit depth
+// of the ray through the box - instead of one compact row each.  8 dwords = one s_load_dwordx8.  The
+// test only NOMINATES faces: a nominated face is judged from its own parallelogram row like any other
+// candidate, so the box may idealise the true faces by up to DevScene::box_slack (a wall whose
+// vertices wobble by 1e-6 still joins its box).  Faces are numbered code = 2 * axis + side (side 0:
+// the low plane, 1: the high one); `present` has bit `code` set when the scene holds that face.  A
+// face's candidate id is base + code with base = n_prims + 1 + 8 * box: ids ABOVE every primitive id,
+// translated to the face's first triangle after the loops through DevScene::box_face_id.  The id
+// n_prims itself means "a face of some box, which one is within the error band": every candidate of
+// such a ray is then settled in double precision.
+struct BoxRow {
+    float lox, loy, loz, hix;
+    float hiy, hiz;
+    uint32_t present;
+    uint32_t base;
+};
+
 // Data needed once a triangle has won: unit normal (mesh.py:140), owner, certain-accept cut.
 struct TriAux {
     float nx, ny, nz;   // normalize(ab x ac), rounded from double
     float det_hi;       // |N.d| at or above this certainly passes the 1e-6 cut
     int32_t obj;        // index into scene.objects
     int32_t face;       // face index inside its mesh
-    float tag;          // ray-origin tag: +(id + 1) of the first triangle of this triangle's parallelogram row when it is
-                        // that first triangle, -(id + 1) when it is the second; 0 for a triangle in no such row
+    uint32_t tag;       // what a ray that starts on this triangle needs to know about it (see kTag*): the id of the first
+                        // triangle of its parallelogram row, which of the row's two triangles it is, the row's box face; 0: none
     int32_t pair_row;   // index into quad_rows of the parallelogram row this triangle heads (it is the row's first), else -1
 };
 
@@ -67,6 +85,13 @@ struct SphRow {
     float r;
     int32_t gprim;   // = sphere index
 };
+
+// Ray-origin tag (TriAux::tag, carried from a hit to the ray that leaves it):
+//   bits 0-12   id + 1 of the first triangle of the origin's parallelogram row (0: the origin is in no such row)
+//   bits 14-23  1 + 8 * box + code when that row is a face of a box (0: it is not)
+//   bit  31     the origin is the row's SECOND triangle (the side u < 0 of the diagonal)
+constexpr uint32_t kTagIdMask = 0x1FFFu, kTagBoxShift = 14, kTagBoxMask = 0x3FFu, kTagSecond = 0x80000000u;
+constexpr int kMaxBoxes = 64;
 
 struct MatRow {      // 8 dwords per object
     float r, g, b, emission, smoothness, transmittance, ior, r0;  // r0 = ((1-ior)/(1+ior))^2
@@ -123,6 +148,14 @@ struct DevScene {
     // camera: float32 position and its double-precision residue (pinhole rays come from k_raygen's table)
     float cam_pos[3], cam_res[3];
     const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale; int32_t pad0;   // environment: RGBA8 texels, row-major
+    // ---- boxes (see BoxRow)
+    const BoxRow *box_rows;        // [n_boxes]
+    const int32_t *box_face_id;    // [8 * n_boxes] by 8 * box + code: global id of the face's first triangle, -1 = no such face
+    const TriRow *box_face_rows;   // [8 * n_boxes] by 8 * box + code: the face's parallelogram row (a dead row where there is none)
+    int32_t n_boxes;
+    float box_slack;               // how far (per coordinate) a point of a true face may lie from the box's ideal face
+    float box_tilt;                // bound on the sine of the angle between a true face's normal and its axis
+    int32_t pad1;
     // ---- the few huge spheres, the hierarchy
     const int32_t *big_sph;                           // sphere indices evaluated in float64
     const TriRow *leaf_rows;                          // hierarchy: triangle rows in leaf order

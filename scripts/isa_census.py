@@ -9,7 +9,7 @@ s_waitcnt / s_nop 0.2, memory instructions 1.
 import re, sys, collections
 
 FULL = ("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_xor_b32", "v_and_b32",
-        "v_or_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32", "v_accvgpr")
+        "v_or_b32", "v_lshrrev_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32", "v_accvgpr")
 TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
 
 
