@@ -26,7 +26,7 @@ namespace rt {
 // render kernel adds the per-wave totals to a global array at its end.  In ordinary builds PROF
 // compiles to nothing and no LDS is declared.
 enum { kProfHandout = 0, kProfBegin, kProfRaySetup, kProfSpheres, kProfBigSpheres, kProfQuadRows, kProfSlabRows, kProfTriRows,
-       kProfJudge, kProfSettle, kProfRecord, kProfSky, kProfDraws, kProfBounce, kProfAccum, kProfStats, kProfCount };
+       kProfJudge, kProfSettle, kProfRecord, kProfSky, kProfDraws, kProfBounce, kProfAccum, kProfStats, kProfWalk, kProfLeaves, kProfCount };
 #ifdef RT_SECTION_TIMERS
 __shared__ unsigned g_prof_acc[4][kProfCount];
 __shared__ unsigned g_prof_last[4];
@@ -659,7 +659,7 @@ RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
             }
         }
         if (!Sink::kPerTriangle) PROF(kProfQuadRows);
-        if (!Sink::kPerTriangle) box_loop(S, r, sink);
+        if (!Sink::kPerTriangle) { box_loop(S, r, sink); PROF(kProfSlabRows); }
         if (!Sink::kPerTriangle && S.slab_counts != 0) {
             const int nx = (int)(S.slab_counts & 1023u), ny = (int)((S.slab_counts >> 10) & 1023u), nz = (int)(S.slab_counts >> 20);
             slab_loop<0>(S.slab_rows, 0, nx, r, sink);
@@ -750,6 +750,7 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
             ++visited;
             bc.nodes++;
         }
+        PROF(kProfWalk);
         if (leaf >= 0) {
             const int first = leaf >> 4, cnt0 = leaf & 15;
             const int first2 = leaf2 >= 0 ? leaf2 >> 4 : 0, cnt = cnt0 + (leaf2 >= 0 ? leaf2 & 15 : 0);
@@ -762,6 +763,7 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
                 sink(tl, cur.gprim);
             }
         }
+        PROF(kProfLeaves);
         // a lane that stopped before a second leaf has budget left: it goes round again
     }
 }

@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                 // resumable query: begin it if none is open, walk one slice, finish it when the walk is through
                 const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio);
                 const RayResidue rr = path_residue(S, A.ray_res, p);
+                PROF(kProfRaySetup);
                 if (!walking) {
                     walking = true;
                     walk_node = -1;
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                     h = hit_finish<TRI, HAS_SPH, STRICT>(S, ray, rr, first, second_pass, nullptr);
                     bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
                     alive = path_shade(S, p, A.max_bounces, h, er, eg, eb, l_sky);
+                    PROF(kProfBounce);
                     l_rays += 1u;
                     rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0);
                 }

@@ -7,20 +7,27 @@ sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import helpers as h
 from raytracing_amd.backend.lib import HipBackend
 NAMES = ["handout", "begin", "ray_setup", "spheres", "big_spheres", "quad_rows", "slab_rows", "tri_rows", "judge", "settle",
-         "record", "sky", "draws", "bounce", "accum", "stats"]
+         "record", "sky", "draws", "bounce", "accum", "stats", "walk", "leaves"]
 name = sys.argv[1] if len(sys.argv) > 1 else "room"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 be = HipBackend(0)
-be.set_scene(h.packed_scene(name))
+if name.startswith("horse"):   # room + the chess horse, every face split in four `level` times: horse6 = 1.18 M triangles
+    import dataclasses
+    base = h.packed_scene("room_horse")
+    lv = int(name[5:] or 6)
+    sc = base.with_subdivided_mesh(base.n_meshes - 1, lv) if lv else base
+    be.set_scene(dataclasses.replace(sc, library_bvh=True))
+else:
+    be.set_scene(h.packed_scene(name))
 W, H = 1920, 1080
 be.resize(W, H)
 be.render(W, H, 0, 4, 8, 1); be.synchronize()
 be.reset_stats()
 be.render(W, H, 0, spp, 8, 1); be.synchronize()
 st = be.stats()
-out = (C.c_uint64 * 16)()
+out = (C.c_uint64 * 18)()
 be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
-be.lib.rt_debug_section_cycles(be.handle, out, 16)
+be.lib.rt_debug_section_cycles(be.handle, out, 18)
 tot = sum(out)
 iters = st["rays"] / 64.0
 print(f"{name} {spp} spp: kernel {st['kernel_ms']:.2f} ms, rays {st['rays']}, wave-iterations {iters:.3e}, cycles/iteration (wave view) {tot / iters:.0f}")

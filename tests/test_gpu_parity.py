@@ -771,10 +771,12 @@ def test_pair_rows_with_bounce_rays(backend, monkeypatch, rotate):
         want = h.oracle_intersect(sc, o, d, origin_prim=g)
     want_free = h.oracle_intersect(sc, o, d)
     results = {}
-    for env in (None, "RAYTRACING_AMD_NO_SLABS", "RAYTRACING_AMD_NO_QUADS"):
+    for env in (None, "RAYTRACING_AMD_NO_BOXES", "RAYTRACING_AMD_NO_SLABS", "RAYTRACING_AMD_NO_QUADS"):
         if env:
             monkeypatch.setenv(env, "1")
         backend.set_scene(sc)
+        if env is None:   # the room's walls and its lamp are two boxes when they stand along the axes
+            assert backend.scene_layout()["boxes"] == (0 if rotate else 2)
         results[env] = backend.intersect(o, d, origin_prim=g)
         free = backend.intersect(o, d)
         if env:
@@ -953,6 +955,137 @@ def test_random_soup_of_every_row_kind(backend, seed):
     backend.set_scene(dataclasses.replace(sc, library_bvh=True))
     _check_hits(backend.intersect(o, d), want)
     _check_hits(backend.intersect(o2, d2, origin_prim=g2), want2)
+
+
+def _box_faces(lo, hi, faces, rng, wobble=0.0):
+    """Triangles (two per face) of the faces `faces` (codes 2 * axis + side) of the box [lo, hi]."""
+    out = []
+    for f in faces:
+        ax, side = f // 2, f % 2
+        b, c = [i for i in range(3) if i != ax]
+        p = np.zeros((4, 3))
+        p[:, ax] = hi[ax] if side else lo[ax]
+        p[:, b] = [lo[b], hi[b], hi[b], lo[b]]
+        p[:, c] = [lo[c], lo[c], hi[c], hi[c]]
+        if wobble:
+            e1 = rng.uniform(-wobble, wobble, 3); e2 = rng.uniform(-wobble, wobble, 3); a0 = rng.uniform(-wobble, wobble, 3)
+            p = p + a0 + np.outer([0, 1, 1, 0], e1) + np.outer([0, 0, 1, 1], e2)   # still a parallelogram
+        k = int(rng.integers(0, 4))
+        q = np.roll(p, k, axis=0)
+        if rng.uniform() < 0.5:
+            q = q[::-1]
+        out += [np.concatenate([q[0], q[1], q[2]]), np.concatenate([q[0], q[2], q[3]])]
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_box_rows(backend, monkeypatch, seed):
+    """Axis-aligned boxes whose faces are parallelogram rows are tested with one slab test per box.  A
+    scene of closed, open, wobbling, thin, nested and touching boxes among lone triangles and spheres:
+    free rays (random; aimed at box edges and corners, where the entered face is within the error
+    band; from inside the boxes) and bounce rays that leave the faces (next to edges and diagonals,
+    grazing) give the oracle's hits, with the box rows and without them."""
+    import dataclasses
+
+    base = h.packed_scene("room")
+    rng = np.random.default_rng(500 + seed)
+    boxes = [  # lo, hi, faces, wobble
+        ((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), [0, 1, 2, 3, 5], 1e-6),          # a room, open at z = -1, walls not quite flat
+        ((-0.5, 0.9, -0.5), (0.5, 0.97, 0.5), [0, 1, 2, 3, 4, 5], 0.0),        # a thin closed box under its ceiling
+        ((-0.6, -1.0, -0.2), (-0.1, -0.3, 0.6), [0, 1, 3, 4, 5], 0.0),         # a box standing on the floor (no bottom)
+        ((-0.1, -1.0, -0.2), (0.5, -0.5, 0.6), [0, 1, 2, 3, 4, 5], 0.0),       # its neighbour: they touch in the plane x = -0.1
+        ((-0.45, -0.8, 0.0), (-0.25, -0.5, 0.4), [0, 1, 2, 3, 4, 5], 0.0),     # a box inside the first
+        ((0.6, 0.0, -0.9), (0.9, 0.4, -0.5), [0, 2, 4, 5], 0.0),               # four faces only
+        ((0.6, -0.9, -0.9), (0.9, -0.6, -0.5), [1, 3, 4], 0.0),                # three faces: stays compact rows
+    ]
+    meshes = [np.array(_box_faces(np.array(lo), np.array(hi), f, rng, w)) for lo, hi, f, w in boxes]
+    lone = []
+    for _ in range(12):
+        c = rng.uniform(-0.9, 0.9, 3)
+        lone.append(np.concatenate([c + rng.normal(scale=0.2, size=3) for _ in range(3)]))
+    meshes.append(np.array(lone))
+    tv = np.concatenate(meshes)
+    begin = np.concatenate([[0], np.cumsum([len(m) for m in meshes])]).astype(np.int32)
+    aabb = np.array([np.concatenate([m.reshape(-1, 3).min(0), m.reshape(-1, 3).max(0)]) for m in meshes])
+    n_mesh = len(meshes)
+    sph = np.array([[0.3, 0.2, 0.1, 0.25], [-0.7, 0.5, 0.6, 0.2]])
+    n_sph = len(sph)
+    sc = dataclasses.replace(base, obj_kind=np.array([1] * n_mesh + [0] * n_sph, np.int32),
+                             obj_index=np.array(list(range(n_mesh)) + list(range(n_sph)), np.int32),
+                             materials=np.ascontiguousarray(np.tile(base.materials[:1], (n_mesh + n_sph, 1))),
+                             spheres=sph, sphere_obj=np.arange(n_sph, dtype=np.int32) + n_mesh, mesh_aabb=np.ascontiguousarray(aabb),
+                             mesh_obj=np.arange(n_mesh, dtype=np.int32), mesh_tri_begin=begin, tri_verts=np.ascontiguousarray(tv),
+                             object_names=["x"] * (n_mesh + n_sph))
+    # free rays
+    corners = np.array([[(lo if (k >> a) & 1 == 0 else hi)[a] for a in range(3)] for lo, hi, _, _ in boxes for k in range(8)])
+    o, d = [], []
+    for i in range(30000):
+        kind = i % 5
+        org = rng.uniform(-1.4, 1.4, 3) if kind != 4 else rng.uniform(-0.95, 0.95, 3)
+        if kind in (0, 4):
+            dd = rng.normal(size=3)
+        elif kind == 1:      # at a corner of a box, or next to it
+            dd = corners[int(rng.integers(0, len(corners)))] + rng.choice([0.0, 1e-7, 1e-5, 1e-3]) * rng.normal(size=3) - org
+        elif kind == 2:      # at a point of an edge of a box
+            a, b = corners[8 * int(rng.integers(0, len(boxes))):][:8][[0, int(rng.choice([1, 2, 4]))]]
+            dd = a + (b - a) * rng.uniform() + rng.choice([0.0, 1e-7, 1e-5]) * rng.normal(size=3) - org
+        else:                # along an axis plane (one direction component tiny or zero)
+            dd = rng.normal(size=3); dd[int(rng.integers(0, 3))] = rng.choice([0.0, 1e-20, 1e-9, 1e-5])
+        if np.linalg.norm(dd) < 1e-6:
+            dd = rng.normal(size=3)
+        o.append(org); d.append(dd / np.linalg.norm(dd))
+    o = np.array(o).astype(np.float32).astype(np.float64)
+    d = np.array(d).astype(np.float32).astype(np.float64)
+    want = h.oracle_intersect(sc, o, d)
+    # bounce rays: from points of the faces (next to edges and diagonals too), any direction or grazing
+    tris = tv.reshape(-1, 3, 3)
+    o2, d2, g2 = [], [], []
+    for _ in range(20000):
+        t = int(rng.integers(0, len(tris)))
+        A, B, C = tris[t]
+        e = int(rng.integers(0, 3))
+        P, Q, S = (A, B, C) if e == 0 else ((B, C, A) if e == 1 else (C, A, B))
+        s, eps = rng.uniform(0.02, 0.98), rng.choice([0.0, 1e-7, 1e-5, 1e-3, 0.3])
+        p = P * (1 - s) + Q * s + (S - (P + Q) / 2) * eps
+        n = np.cross(B - A, C - A); n /= np.linalg.norm(n)
+        if rng.uniform() < 0.5:
+            dd = rng.normal(size=3)
+        else:
+            dd = ((P + Q) / 2 - S) * rng.uniform(-2, 2) + n * rng.choice([-1, 1]) * rng.choice([1e-6, 1e-4, 1e-2])
+        o2.append(p + n * rng.choice([0.0, 0.0, 1e-7, -1e-7, 3e-4, -3e-4])); d2.append(dd / np.linalg.norm(dd)); g2.append(n_sph + t)
+    o2 = np.array(o2).astype(np.float32).astype(np.float64)
+    d2 = np.array(d2).astype(np.float32).astype(np.float64)
+    g2 = np.array(g2, np.int32)
+    with h.origin_rule():
+        want2 = h.oracle_intersect(sc, o2, d2, origin_prim=g2)
+    for env in (None, "RAYTRACING_AMD_NO_BOXES"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        with h.linear_tables():
+            backend.set_scene(sc)
+        lay = backend.scene_layout()
+        if env:
+            monkeypatch.delenv(env)
+        assert lay["boxes"] == (0 if env else 6) and lay["bvh_nodes"] == 0
+        if env is None:
+            assert lay["box_slack"] < 1e-5 and sum(lay["compact_rows"]) >= 3
+        _check_hits(backend.intersect(o, d), want)
+        _check_hits(backend.intersect(o2, d2, origin_prim=g2), want2)
+    assert (want["obj"] >= 0).mean() > 0.6 and (want2["obj"] >= 0).mean() > 0.5
+    # and through the render path's own record: whole paths in this scene, hit for hit (the bounce rays there
+    # carry what the hit before them learnt about their origin)
+    backend.set_scene(sc)
+    W, H, b = 64, 36, 6
+    xys = np.array([(x, y, s_) for x in range(W) for y in range(H) for s_ in range(2)], np.int32)
+    tr = backend.trace_paths(xys, W, H, b, h.SEED_RENDER)
+    idx = [(i, k) for i in range(len(xys)) for k in range(1, int(tr["n_seg"][i]))]
+    ii, kk = np.array([q[0] for q in idx]), np.array([q[1] for q in idx])
+    org, drs = tr["org"][ii, kk].astype(np.float64), tr["dir"][ii, kk].astype(np.float64)
+    origin = _gprim_of(sc, tr["obj"][ii, kk - 1], tr["prim"][ii, kk - 1])
+    with h.origin_rule():
+        w = h.oracle_intersect(sc, org, drs, origin_prim=origin)
+    bad = (tr["obj"][ii, kk] != w["obj"]) | (tr["prim"][ii, kk] != w["prim"])
+    assert len(ii) > 4000 and not bad.any(), f"{int(bad.sum())} of {len(bad)} bounce segments differ in hit identity"
 
 
 def _gprim_of(sc, obj, prim):
