@@ -101,7 +101,14 @@ enum {
     RT_SCENE_NO_COMPACT_ROWS = 2,  /* no compact rows for parallelograms in axis-perpendicular planes */
     RT_SCENE_NO_LINEAR_SPLIT = 4,  /* hierarchy scenes: scene-sized triangles go into the hierarchy too */
     RT_SCENE_NO_LDS_TOP = 8,       /* hierarchy scenes: top levels read from memory instead of LDS */
-    RT_SCENE_NO_BOX_ROWS = 16      /* no box rows (axis-aligned boxes whose faces are tested with one slab test) */
+    RT_SCENE_NO_BOX_ROWS = 16,     /* no box rows (axis-aligned boxes whose faces are tested with one slab test) */
+    /* Moved meshes (upstream: Mesh.update_transformed_vertices, src/mesh/mesh.py:178-209, which rebuilds
+     * nothing because it has no acceleration structure): when the context's current hierarchy was built
+     * by rt_set_scene for the same meshes (same triangle counts per mesh, same leaf size), keep its
+     * topology and leaf order and only refit the boxes to the new vertices; every table is uploaded
+     * again.  Hits are those of a rebuilt hierarchy (any valid hierarchy gives the same hits); a refitted
+     * one may be slower to walk after large deformations.  Ignored when there is nothing to refit. */
+    RT_SCENE_REFIT = 32
 };
 
 /* Depth-first ("threaded") BVH node: if the ray misses the box, or after a leaf has been
@@ -290,7 +297,8 @@ int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t see
 /* How rt_set_scene laid the current scene's triangles out (no upstream counterpart; tests and tuning):
  * out[0] parallelogram rows (padded), [1] of which in general position, [2..4] compact rows per axis
  * x, y, z (padded to even), [5] single-triangle rows (padded), [6] boxes, [7] hierarchy nodes;
- * n_out >= 8.  *box_slack (optional) = the largest distance of a true box face from its ideal one. */
+ * n_out >= 8; with n_out >= 9, out[8] = 1 when the last rt_set_scene refitted the hierarchy (RT_SCENE_REFIT).
+ * *box_slack (optional) = the largest distance of a true box face from its ideal one. */
 int rt_debug_scene_layout(rt_ctx *ctx, int32_t *out, int32_t n_out, float *box_slack);
 
 /* Parity / diagnostic hook: traces n_paths whole paths, one device thread each, with the same

@@ -12,7 +12,7 @@ from typing import Optional
 
 import numpy as np
 
-from .packer import PackedScene, RtSceneDesc
+from .packer import PackedScene, RtSceneDesc, RT_SCENE_REFIT
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_rt_hip.so")
 
@@ -145,8 +145,13 @@ class HipBackend:
             pass
 
     # -- scene ----------------------------------------------------------------------------------
-    def set_scene(self, packed: PackedScene) -> None:
+    def set_scene(self, packed: PackedScene, refit: bool = False) -> None:
+        """Upload a scene.  ``refit``: the scene differs from the current one only in vertex positions
+        (moved meshes): keep the hierarchy's topology and refit its boxes (``RT_SCENE_REFIT``; the
+        library checks that the meshes match and builds anew when they do not)."""
         d = packed.desc()
+        if refit:
+            d.flags |= RT_SCENE_REFIT
         self._check(self.lib.rt_set_scene(self.handle, C.byref(d)))
         self._scene_keepalive = packed
 
@@ -264,11 +269,11 @@ class HipBackend:
 
     def scene_layout(self) -> dict:
         """How ``rt_set_scene`` laid the current scene's triangles out (tests and tuning)."""
-        out = (C.c_int32 * 8)()
+        out = (C.c_int32 * 9)()
         slack = C.c_float(0.0)
-        self._check(self.lib.rt_debug_scene_layout(self.handle, out, 8, C.byref(slack)))
+        self._check(self.lib.rt_debug_scene_layout(self.handle, out, 9, C.byref(slack)))
         return dict(quad_rows=out[0], quad_general=out[1], compact_rows=(out[2], out[3], out[4]), tri_rows=out[5],
-                    boxes=out[6], bvh_nodes=out[7], box_slack=float(slack.value))
+                    boxes=out[6], bvh_nodes=out[7], refitted=bool(out[8]), box_slack=float(slack.value))
 
     def raytrace(self, origins, directions, max_bounces: int, seed: int = 0, inside=None, first_depth: int = 0,
                  sample: int = 0, stream_begin: int = 0) -> np.ndarray:

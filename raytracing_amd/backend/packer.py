@@ -68,7 +68,7 @@ class RtSceneDesc(C.Structure):
 
 
 # rt_scene_desc.flags
-RT_SCENE_NO_PAIR_ROWS, RT_SCENE_NO_COMPACT_ROWS, RT_SCENE_NO_LINEAR_SPLIT, RT_SCENE_NO_LDS_TOP, RT_SCENE_NO_BOX_ROWS = 1, 2, 4, 8, 16
+RT_SCENE_NO_PAIR_ROWS, RT_SCENE_NO_COMPACT_ROWS, RT_SCENE_NO_LINEAR_SPLIT, RT_SCENE_NO_LDS_TOP, RT_SCENE_NO_BOX_ROWS, RT_SCENE_REFIT = 1, 2, 4, 8, 16, 32
 
 
 def layout_switches() -> dict:

@@ -104,6 +104,12 @@ struct rt_ctx {
     double *post_scratch = nullptr;   // rt_postprocess_noalloc: this GPU's copy of the static scratch array
     DevBuf wf_rays[2], wf_paths, wf_hits, wf_radiance, wf_counters, wf_partials;   // wavefront form (hierarchy scenes)
     DevBuf ray_dir, ray_res; int ray_w = 0, ray_h = 0;   // camera-ray table of the current scene at ray_w x ray_h
+    // The hierarchy rt_set_scene last BUILT (host copy: threaded depth-first nodes, leaf order, which triangles stay in
+    // the linear tables) and what it was built for: a later scene that differs only in vertex positions can be
+    // refitted over it (RT_SCENE_REFIT)
+    std::vector<rt_bvh_node> topo_nodes; std::vector<int32_t> topo_order, topo_mesh_begin; std::vector<char> topo_linear;
+    int32_t topo_leaf = 0; uint32_t topo_flags = 0;
+    bool last_refit = false;
     DevBuf isect_in, isect_out;          // rt_intersect_batch staging, grow-only (one call in flight per context)
     std::vector<EventPair> timed;        // recorded around render launches, not yet read
     std::vector<EventPair> spare_events; // read and ready for reuse (events are created once, not per launch)
@@ -316,6 +322,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     if (!use_bvh && n_gprim > 4096)
         return fail(c, RT_ERR_UNSUPPORTED, "%lld primitives without triangles: the linear sphere walk takes at most 4096", n_gprim);
     std::vector<rt_bvh_node> bvh_nodes; std::vector<int32_t> bvh_order;
+    bool refitted = false;
     std::vector<char> linear_tri;   // with a hierarchy: triangles that stay in the linear table instead (empty = none)
     if (use_bvh) {
         if (d->n_bvh_nodes > 0) {
@@ -325,6 +332,13 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             if (!why.empty()) return fail(c, RT_ERR_INVALID_ARG, "bad hierarchy: %s", why.c_str());
             bvh_nodes.assign(nn, nn + d->n_bvh_nodes);
             bvh_order.assign(d->bvh_tri_index, d->bvh_tri_index + d->n_tris);
+        } else if ((d->flags & RT_SCENE_REFIT) && !c->topo_nodes.empty() && (int64_t)c->topo_linear.size() == d->n_tris &&
+                   c->topo_mesh_begin == std::vector<int32_t>(d->mesh_tri_begin, d->mesh_tri_begin + d->n_meshes + 1) &&
+                   c->topo_leaf == d->bvh_leaf_size && c->topo_flags == (d->flags & RT_SCENE_NO_LINEAR_SPLIT)) {
+            // same meshes, moved vertices: the topology and leaf order of the hierarchy built last time, boxes refitted
+            bvh_nodes = c->topo_nodes; bvh_order = c->topo_order; linear_tri = c->topo_linear;
+            bvh::refit(bvh_nodes, bvh_order, d->tri_verts);
+            refitted = true;
         } else {
             // Triangles that span a sizeable part of the scene (walls, floors) would sit in leaves near
             // the root whose boxes nearly every ray enters, and each test there costs four divergent
@@ -362,8 +376,12 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             // leaf target: default 3 (measured 1 ... 8 on 310 ... 1.18 M triangles)
             b.run(d->n_tris, d->tri_verts, d->bvh_leaf_size > 0 ? d->bvh_leaf_size : 3, &rest, d->build_threads);
             bvh_nodes.swap(b.nodes); bvh_order.swap(b.order);
+            c->topo_nodes = bvh_nodes; c->topo_order = bvh_order; c->topo_linear = linear_tri;
+            c->topo_mesh_begin.assign(d->mesh_tri_begin, d->mesh_tri_begin + d->n_meshes + 1);
+            c->topo_leaf = d->bvh_leaf_size; c->topo_flags = d->flags & RT_SCENE_NO_LINEAR_SPLIT;
         }
     }
+    c->last_refit = refitted;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     // From here on the tables of the previous scene are being replaced (uploads may free and
@@ -1344,6 +1362,7 @@ extern "C" int rt_debug_scene_layout(rt_ctx *c, int32_t *out, int32_t n_out, flo
     out[0] = S.n_quad_rows_padded; out[1] = S.n_quad_general;
     out[2] = (int32_t)(S.slab_counts & 1023u); out[3] = (int32_t)((S.slab_counts >> 10) & 1023u); out[4] = (int32_t)(S.slab_counts >> 20);
     out[5] = S.n_tri_rows_padded; out[6] = S.n_boxes; out[7] = S.n_bvh_nodes;
+    if (n_out >= 9) out[8] = c->last_refit ? 1 : 0;
     if (box_slack) *box_slack = S.box_slack;
     return RT_OK;
 }

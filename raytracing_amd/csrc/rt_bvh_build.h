@@ -275,6 +275,39 @@ struct Builder {
 // is visited first, so a walk meets near geometry before far geometry and its depth bound prunes
 // the rest.  Subtree sizes do not depend on the order, so skip links follow from the source's.
 // `src` must have passed validate() (or come from Builder).
+// Refit: the boxes of an existing hierarchy (threaded depth-first order, as Builder leaves it) for
+// moved vertices, topology and leaf order unchanged.  A node's subtree is [i, skip): going through
+// the nodes backwards meets every child before its parent.  Boxes are rounded outward exactly as
+// Builder::run rounds them, so a refitted hierarchy is as conservative as a built one.
+inline void refit(std::vector<rt_bvh_node> &nodes, const std::vector<int32_t> &order, const double *verts) {
+    const int32_t n = (int32_t)nodes.size();
+    for (int32_t i = n - 1; i >= 0; --i) {
+        rt_bvh_node &nd = nodes[i];
+        Box bb; bb.reset();
+        if (nd.tri_begin_count >= 0) {
+            const int32_t begin = nd.tri_begin_count >> 4, cnt = nd.tri_begin_count & 15;
+            for (int32_t k = begin; k < begin + cnt; ++k) {
+                const double *v = verts + 9 * (size_t)order[k];
+                Box b;
+                for (int a = 0; a < 3; ++a) {
+                    double lo = std::min({v[a], v[3 + a], v[6 + a]}), hi = std::max({v[a], v[3 + a], v[6 + a]});
+                    if (!std::isfinite(lo) || !std::isfinite(hi)) { lo = -3.0e38; hi = 3.0e38; }   // never culled
+                    b.lo[a] = round_down(lo); b.hi[a] = round_up(hi);
+                }
+                bb.grow(b);
+            }
+        } else {
+            const int32_t end = nd.skip < 0 ? n : nd.skip;
+            for (int32_t c = i + 1; c < end; c = nodes[c].skip < 0 ? n : nodes[c].skip) {
+                Box b;
+                for (int a = 0; a < 3; ++a) { b.lo[a] = nodes[c].lo[a]; b.hi[a] = nodes[c].hi[a]; }
+                bb.grow(b);
+            }
+        }
+        Builder::set_box(nd, bb);
+    }
+}
+
 inline void rethread(const std::vector<rt_bvh_node> &src, int octant, std::vector<rt_bvh_node> &dst) {
     const int32_t n = (int32_t)src.size();
     dst.clear(); dst.reserve(n);

@@ -184,7 +184,8 @@ class Scene:
         key = (self.fingerprint(), device)
         if self._backend is None or self._packed_key != key:
             be = self._backend if (self._backend is not None and self._backend.device == device) else HipBackend(device)
-            be.set_scene(pack_scene(self))
+            # (refit: a scene that only moved keeps its hierarchy's topology; the library checks that it is the same meshes)
+            be.set_scene(pack_scene(self), refit=True)
             self._backend, self._packed_key = be, key
         return self._backend
 
@@ -346,7 +347,7 @@ class Renderer:
         be = self._backend if self._backend is not None else HipBackend(self.device)
         key = (id(self.scene), self.scene.fingerprint())
         if self._scene_key != key:
-            be.set_scene(pack_scene(self.scene))
+            be.set_scene(pack_scene(self.scene), refit=True)
             self._scene_key = key
         be.clear_stop()
         be.reset_stats()
@@ -477,7 +478,7 @@ class Renderer:
 
             key = (id(scene), scene.fingerprint())
             if self._scene_key != key:
-                self._backend.set_scene(pack_scene(scene))
+                self._backend.set_scene(pack_scene(scene), refit=True)
                 self._scene_key = key
             return self._backend
         return scene._device_scene(self.device)

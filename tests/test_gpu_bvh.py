@@ -303,3 +303,68 @@ def test_wavefront_form_traces_the_same_paths(backend, monkeypatch):
     # pruning bound): the two forms cut their walks differently
     for k in ("tri_tests", "bvh_node_tests"):
         assert abs(sa[k] - sw[k]) <= 0.01 * sa[k], (k, sa[k], sw[k])
+
+
+def test_refit_for_moved_mesh_equals_rebuild(backend):
+    """Moved meshes (upstream: the mesh setters, mesh.py:178-209): with RT_SCENE_REFIT the library keeps the
+    topology and leaf order of the hierarchy it built for the same meshes and only refits the boxes.
+    On the 74 k-triangle mesh, turned, shifted and bent: the refitted scene's hits are those of a scene
+    built from scratch and of the oracle (identity exact), bounce rays included; the time of both
+    uploads is printed.  A scene with other meshes is built anew however the flag is set."""
+    import time
+
+    base = h.packed_scene("room_horse")
+    sc0 = base.with_subdivided_mesh(base.n_meshes - 1, 4)
+    m = base.n_meshes - 1
+    b0, b1 = int(sc0.mesh_tri_begin[m]), int(sc0.mesh_tri_begin[m + 1])
+    assert b1 - b0 > 70000
+
+    def moved(sc, angle, shift, bend):
+        tv = sc.tri_verts.copy()
+        p = tv[b0:b1].reshape(-1, 3)
+        c = p.mean(0)
+        ca, sa = np.cos(angle), np.sin(angle)
+        R = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]])
+        q = (p - c) @ R.T
+        q[:, 0] += bend * q[:, 1] ** 2          # not a rigid motion: the boxes really have to be refitted
+        p[:] = q + c + np.asarray(shift)
+        aabb = sc.mesh_aabb.copy()
+        aabb[m] = np.concatenate([p.min(0), p.max(0)])
+        return dataclasses.replace(sc, tri_verts=np.ascontiguousarray(tv), mesh_aabb=aabb)
+
+    backend.set_scene(dataclasses.replace(sc0, library_bvh=True))
+    assert not backend.scene_layout()["refitted"]
+    o, d = _random_rays(8000, 77, scale=1.0)
+    _, po, pd = _path_rays()
+    o, d = np.concatenate([o, po[:4000]]), np.concatenate([d, pd[:4000]])
+    for angle, shift, bend in [(0.4, (0.05, 0.0, -0.1), 0.0), (2.2, (-0.2, 0.02, 0.1), 0.3)]:
+        sc1 = dataclasses.replace(moved(sc0, angle, shift, bend), library_bvh=True)
+        t0 = time.perf_counter(); backend.set_scene(sc1, refit=True); t_refit = time.perf_counter() - t0
+        lay = backend.scene_layout()
+        assert lay["refitted"] and lay["bvh_nodes"] > 10000
+        got = backend.intersect(o, d)
+        hit = got["obj"] >= 0
+        o2 = got["pos"][hit].astype(np.float32).astype(np.float64)
+        g2 = got["gprim"][hit].astype(np.int32)
+        d2 = np.random.default_rng(5).normal(size=o2.shape)
+        d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32).astype(np.float64)
+        got2 = backend.intersect(o2, d2, origin_prim=g2)
+        t0 = time.perf_counter(); backend.set_scene(sc1); t_build = time.perf_counter() - t0
+        assert not backend.scene_layout()["refitted"]
+        fresh, fresh2 = backend.intersect(o, d), backend.intersect(o2, d2, origin_prim=g2)
+        for a, b in ((got, fresh), (got2, fresh2)):
+            assert np.array_equal(a["obj"], b["obj"]) and np.array_equal(a["prim"], b["prim"])
+            assert np.array_equal(a["t"], b["t"])              # the same hit record, bit for bit
+        want = h.oracle_intersect(sc1, o, d)
+        _check_hits(got, want)
+        with h.origin_rule():
+            _check_hits(got2, h.oracle_intersect(sc1, o2, d2, origin_prim=g2))
+        assert (want["obj"] == sc1.mesh_obj[m]).sum() > 300
+        print(f"\n{b1 - b0} triangles moved: upload with refit {1e3 * t_refit:.0f} ms, with a new hierarchy {1e3 * t_build:.0f} ms "
+              f"(ratio {t_refit / t_build:.2f})")
+        backend.set_scene(sc1, refit=True)                     # the topology kept is the one built last
+        assert backend.scene_layout()["refitted"]
+    # other meshes: nothing to refit
+    backend.set_scene(dataclasses.replace(base.with_subdivided_mesh(m, 3), library_bvh=True), refit=True)
+    assert not backend.scene_layout()["refitted"]
+    _check_hits(backend.intersect(o[:4000], d[:4000]), h.oracle_intersect(base.with_subdivided_mesh(m, 3), o[:4000], d[:4000]))
