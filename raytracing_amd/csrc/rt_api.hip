@@ -1169,6 +1169,12 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
 #ifdef RT_SECTION_TIMERS
     A.prof = A.stats + kStatCount;
 #endif
+#ifdef RT_TUNE
+    {   // tuning builds only (the shipped library reads no environment variable)
+        auto num = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+        A.tune[0] = num("RT_TUNE_SLICE", 8); A.tune[1] = num("RT_TUNE_MORE_BELOW", 16); A.tune[2] = num("RT_TUNE_MORE_TIMES", 1); A.tune[3] = 0;
+    }
+#endif
     if (n_chunks > 1) {
         // grows only; a larger request first drains work that may still read the old buffer
         size_t need = (size_t)total_jobs * 3 * sizeof(float);

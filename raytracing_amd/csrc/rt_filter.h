@@ -516,18 +516,22 @@ RT_DEV TriRow load_tri_row_lane(const TriRow *rows, int i) {
 //
 // Error band.  A computed v is within E(t) = c7i_a |t| + c4i_a of the exact crossing (the compact
 // rows' model); a point of a TRUE face lies within box_slack, per coordinate, of the ideal face.  With
-//     band(t) = c7m |t| + c4m,   c7m = (1.05 c7 + 32 u) max_a |1/d_a|,   c4m = 1.05 (c4 + box_slack) max_a |1/d_a|
-// the following holds for a ray that hits true face f at depth t* > 0 (f's plane being, say, the
-// entry plane of its axis): v_f >= t* - band, every other entry value <= t* + band, every exit
-// value >= t* - band.  Hence v_f is the largest entry value or within 2 band of it; tf - tn >=
-// -2 band; tn + band >= 0; tn - band <= t* + ... so: the entry face is nominated with lower depth
-// bound tn - 3.5 band when min(tf - tn + band(tn) + band(tf), tn + band(tn)) >= 0, under the id of
-// the face whose plane gave tn - or, when the second largest entry value is within 2.5 band of tn
-// (the ray enters near an edge of the box), under the reserved id that opens every candidate.  The
-// exit face likewise.  A nominated face that the scene does not hold, or that is the ray's own
-// origin, is dropped - but only when the nomination is unambiguous.  The origin's own face row is
-// tested on its own, from its parallelogram row, by the caller: that test applies the origin rule
-// at the ray's actual crossing point.
+//     band(t) = c7m |t| + c4m,   c7m = 1.05 c7 max_a |1/d_a| + 16.5 u,   c4m = 1.05 (c4 + box_slack) max_a |1/d_a|
+// take a ray that hits the true face f at depth t* > 0, f's plane being the entry plane of its axis
+// (the exit case mirrors it).  The hit point is within box_slack of the ideal face, so in computed
+// values: v_f >= t* - band, every other entry value <= t* + band, every exit value >= t* - band.
+// Three things follow.  (1) v_f is the largest entry value tn, or within 2 band of it - then the
+// second largest is within 2 band of tn as well.  (2) tf - tn >= -2 band and tn + band >= 0.
+// (3) tn >= v_f >= t* - band and tn <= t* + band: whichever face is hit at the entry, its depth is at
+// least tn - band.  So the entry face is nominated, with lower depth bound tn - 1.25 band, when
+// min(tf - tn + band(tn) + band(tf), tn + band(tn)) >= 0: under the id of the face whose plane
+// gave tn, or - when the second largest entry value is within 2.25 band of tn (the ray enters near an
+// edge of the box) - under the reserved id that opens every candidate of the ray.  The exit face
+// likewise (lower bound tf - 1.25 band).  A nominated face that the scene does not hold, or that is
+// the ray's own origin, is dropped, but only when the nomination is unambiguous.  The origin's own
+// face is tested separately, from its parallelogram row (see box_loop): that test applies the origin
+// rule at the ray's actual crossing point.  A nomination is only that: the judge evaluates the face's
+// true row, and a nominee it refuses opens every candidate (hit_finish).
 // ---------------------------------------------------------------------------------------------
 struct BoxRay {
     float ix, iy, iz, nx, ny, nz;   // 1 / d_a and -o_a / d_a
@@ -542,7 +546,7 @@ RT_DEV BoxRay box_ray(SceneRef S, const Ray &r) {
     a.ix = rcp_(r.dx); a.iy = rcp_(r.dy); a.iz = rcp_(r.dz);
     a.nx = -(r.ox * a.ix); a.ny = -(r.oy * a.iy); a.nz = -(r.oz * a.iz);
     const float imax = max3_(abs_(a.ix), abs_(a.iy), abs_(a.iz));
-    a.c7m = fma_(1.05f, r.c7, 32.0f * kU) * imax;
+    a.c7m = fma_(1.05f * r.c7, imax, 16.5f * kU);   // (the face code written over three mantissa bits moves a value by less than 16 u |v|)
     a.c4m = 1.05f * (r.c4 + S.box_slack) * imax;
     a.dmin = min3_(abs_(r.dx), abs_(r.dy), abs_(r.dz));
     a.amb_id = (uint32_t)S.n_prims;
@@ -584,20 +588,20 @@ RT_DEV void box_row_test(const BoxRow &B, const BoxRay &a, Sink &sink) {
     const float gap = (tf - tn) + (bn + bf);
     {   // entry
         const uint32_t code = f2u(tn) & 7u, id = B.base + code;
-        const bool amb = !(tn - tm > 2.5f * bn);
+        const bool amb = !(tn - tm > 2.25f * bn);
         const bool ok = ((B.present >> code) & 1u) != 0u && id != a.own_id;
         const float x = min_(gap, tn + bn);
         const float y = x * (-kInf);                 // x < 0 -> +inf (not a candidate); x >= 0 -> -inf / NaN
-        const float tl = max3_(fma_(-3.5f, bn, tn), 0.0f, y);
+        const float tl = max3_(fma_(-1.25f, bn, tn), 0.0f, y);
         sink((amb || ok) ? tl : kInf, (int32_t)(amb ? a.amb_id : id));
     }
     {   // exit
         const uint32_t code = f2u(tf) & 7u, id = B.base + code;
-        const bool amb = !(tq - tf > 2.5f * bf);
+        const bool amb = !(tq - tf > 2.25f * bf);
         const bool ok = ((B.present >> code) & 1u) != 0u && id != a.own_id;
         const float x = min_(gap, tf + bf);
         const float y = x * (-kInf);
-        const float tl = max3_(fma_(-3.5f, bf, tf), 0.0f, y);
+        const float tl = max3_(fma_(-1.25f, bf, tf), 0.0f, y);
         sink((amb || ok) ? tl : kInf, (int32_t)(amb ? a.amb_id : id));
     }
 }

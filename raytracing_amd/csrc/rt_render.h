@@ -424,13 +424,18 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                     first.init(S);
                     if (ray_route<TRI>(ray) == kRouteFilter) { hit_begin<TRI, HAS_SPH>(S, ray, rr, first); walk_node = 0; }
                 }
-                if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, kWalkSlice);
+#ifdef RT_TUNE
+                const int walk_slice = A.tune[0], more_below = A.tune[1], more_times = A.tune[2];
+#else
+                constexpr int walk_slice = kWalkSlice, more_below = 16, more_times = 1;
+#endif
+                if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
                 // When only a few lanes are through, closing their queries now would run ~1,000
                 // instructions for them alone: the wave walks one more slice first.  (Measured at
                 // 1.18 M triangles: thresholds 8 / 16 / 24 -> 5.05 / 5.10 / 5.06 against 4.86 G rays/s
                 // without; repeating the extra slice two to four times: 4.97 ... 4.81.)
-                if (__builtin_popcountll(__ballot(walk_node < 0)) < 16) {
-                    if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, kWalkSlice);
+                for (int k = 0; k < more_times && __builtin_popcountll(__ballot(walk_node < 0)) < more_below; ++k) {
+                    if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
                 }
                 if (walk_node < 0) {
                     walking = false;

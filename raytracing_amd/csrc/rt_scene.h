@@ -195,6 +195,9 @@ struct RenderArgs {
     float *partial;           // [n_chunks][rect_w*rect_h][3] when n_chunks > 1, else unused
     unsigned long long *stats;  // kStat* counters
     unsigned long long *prof;   // section-timer totals (diagnostic builds with RT_SECTION_TIMERS), else null
+#ifdef RT_TUNE
+    int32_t tune[4];            // tuning builds only: walk slice, lanes-through threshold for one more slice, how many more
+#endif
 };
 
 enum { kStatRays = 0, kStatPaths, kStatSphTests, kStatTriTests, kStatExact, kStatRefine, kStatSky, kStatShaded,
