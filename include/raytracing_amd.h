@@ -137,11 +137,18 @@ enum {
      * over path queues in memory) instead of the single persistent kernel. */
     RT_RENDER_WAVEFRONT = 1,
     /* Accept a float32 hit depth only when its error BOUND is below 9.5e-6 of the depth, as
-     * rt_intersect_batch does; otherwise redo it in double precision.  Without the flag the render
-     * accepts bounds up to 2e-4 relative (or 1e-5 of the scene size absolute): hit identity is exact
-     * either way, and measured depths agree with upstream's to better than 1e-5 in both modes (the
-     * bound is what differs); the strict mode costs about 15 % of render time. */
-    RT_RENDER_STRICT_DEPTH = 2
+     * rt_intersect_batch does; otherwise redo it in double precision (measured against upstream's
+     * doubles: every depth within 1e-6 relative).  Without the flag the render accepts bounds up to
+     * 2e-4 of the depth, or 1e-5 of the scene size as a distance: hit identity is exact either way;
+     * about 2 in 10,000 depths then differ from upstream's by more than 1e-5 relative (grazing hits
+     * and very short rays), none by more than the bound.  The strict mode costs about 30 % more
+     * render time (a tenth of the rays need the double-precision code). */
+    RT_RENDER_STRICT_DEPTH = 2,
+    /* Render with the one kernel that holds all the code.  Without the flag (and without STRICT_DEPTH)
+     * rt_render runs a lean kernel that sets the few paths needing double-precision settling aside,
+     * traces those again with the full code and folds them in: same paths, same image up to the
+     * rounding of a double-precision sum to float32, faster.  For A/B runs and tests. */
+    RT_RENDER_NO_DEFER = 4
 };
 
 typedef struct rt_stats {
@@ -300,6 +307,11 @@ int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t see
  * n_out >= 8; with n_out >= 9, out[8] = 1 when the last rt_set_scene refitted the hierarchy (RT_SCENE_REFIT).
  * *box_slack (optional) = the largest distance of a true box face from its ideal one. */
 int rt_debug_scene_layout(rt_ctx *ctx, int32_t *out, int32_t n_out, float *box_slack);
+
+/* What the last rt_render call set aside (no upstream counterpart; tests and tuning; synchronises):
+ * out4[0] jobs handed out, [1] paths the lean kernel set aside for the full code, [2] jobs it gave
+ * up (no room left in the list), [3] jobs handed out again. */
+int rt_debug_render_counters(rt_ctx *ctx, uint32_t *out4);
 
 /* Parity / diagnostic hook: traces n_paths whole paths, one device thread each, with the same
  * device functions the render kernel runs (Camera.get_ray + Renderer.raytrace, camera.py:39-50,

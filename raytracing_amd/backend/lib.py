@@ -24,7 +24,7 @@ RT_ERR_STOPPED = 5
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
            "rt_comm_unique_id", "rt_comm_init", "rt_merge",
-           "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms", "rt_debug_scene_layout",
+           "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms", "rt_debug_scene_layout", "rt_debug_render_counters",
            "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_build_bvh_threads", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
 
@@ -35,7 +35,7 @@ class RtRenderParams(C.Structure):
                 ("seed", C.c_uint64), ("flags", C.c_uint32), ("wavefront_paths", C.c_int32)]
 
 
-RT_RENDER_WAVEFRONT, RT_RENDER_STRICT_DEPTH = 1, 2
+RT_RENDER_WAVEFRONT, RT_RENDER_STRICT_DEPTH, RT_RENDER_NO_DEFER = 1, 2, 4
 
 
 class RtPostprocessParams(C.Structure):
@@ -96,6 +96,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_reset_stats.argtypes = [vp]
     lib.rt_debug_uniforms.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int32, fp]
     lib.rt_debug_scene_layout.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32, fp]
+    lib.rt_debug_render_counters.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.rt_debug_trace_paths.argtypes = [vp, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
                                          fp, ip, ip, ip, ip, fp, fp, fp]
     lib.rt_raytrace_batch.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_uint64,
@@ -197,9 +198,11 @@ class HipBackend:
     # -- render ---------------------------------------------------------------------------------
     def render(self, width: int, height: int, sample_begin: int, sample_count: int, max_bounces: int, seed: int,
                rect=None, accum_ptr: int = 0, stream: int = 0, strict_depth: bool = False, wavefront=None,
-               wavefront_paths: int = 0) -> None:
+               wavefront_paths: int = 0, no_defer=None) -> None:
         """``wavefront`` None takes the switch from the environment (RAYTRACING_AMD_WAVEFRONT /
-        RAYTRACING_AMD_WF_PATHS: A/B runs and tests); the library itself reads no environment variable."""
+        RAYTRACING_AMD_WF_PATHS: A/B runs and tests); the library itself reads no environment variable.
+        ``no_defer`` (None: RAYTRACING_AMD_NO_DEFER): the one full kernel instead of the lean kernel
+        plus the set-aside paths (``RT_RENDER_NO_DEFER``)."""
         x0, x1, y0, y1 = rect if rect is not None else (0, width, 0, height)
         if wavefront is None:
             wavefront = bool(os.environ.get("RAYTRACING_AMD_WAVEFRONT"))
@@ -207,7 +210,9 @@ class HipBackend:
                 wavefront_paths = wavefront_paths or int(os.environ.get("RAYTRACING_AMD_WF_PATHS", "0") or 0)
             except ValueError:
                 wavefront_paths = 0
-        flags = (RT_RENDER_WAVEFRONT if wavefront else 0) | (RT_RENDER_STRICT_DEPTH if strict_depth else 0)
+        if no_defer is None:
+            no_defer = bool(os.environ.get("RAYTRACING_AMD_NO_DEFER"))
+        flags = (RT_RENDER_WAVEFRONT if wavefront else 0) | (RT_RENDER_STRICT_DEPTH if strict_depth else 0) | (RT_RENDER_NO_DEFER if no_defer else 0)
         p = RtRenderParams(C.sizeof(RtRenderParams), width, height, x0, x1, y0, y1, sample_begin, sample_count,
                            max_bounces, seed & 0xFFFFFFFFFFFFFFFF, flags, max(0, int(wavefront_paths)))
         self._check(self.lib.rt_render(self.handle, C.byref(p), C.c_void_p(accum_ptr or None), C.c_void_p(stream or None)))
@@ -266,6 +271,12 @@ class HipBackend:
         self._check(self.lib.rt_debug_uniforms(self.handle, pixel, sample, seed, n_segments,
                                                out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def render_counters(self) -> dict:
+        """What the last ``render`` call set aside (tests and tuning; synchronises)."""
+        out = (C.c_uint32 * 4)()
+        self._check(self.lib.rt_debug_render_counters(self.handle, out))
+        return dict(jobs=out[0], paths_set_aside=out[1], jobs_given_up=out[2], jobs_rendered_again=out[3])
 
     def scene_layout(self) -> dict:
         """How ``rt_set_scene`` laid the current scene's triangles out (tests and tuning)."""

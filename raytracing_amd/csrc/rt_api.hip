@@ -100,6 +100,7 @@ struct rt_ctx {
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
+    DevBuf aside, aside_head, dirty, dirty_list;   // rt_render: paths set aside by the lean kernel, jobs it gave up (grow-only)
     DevBuf post_partials;   // rt_postprocess: per-block reduction slots
     double *post_scratch = nullptr;   // rt_postprocess_noalloc: this GPU's copy of the static scratch array
     DevBuf wf_rays[2], wf_paths, wf_hits, wf_radiance, wf_counters, wf_partials;   // wavefront form (hierarchy scenes)
@@ -1127,7 +1128,7 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
         return fail(c, RT_ERR_INVALID_ARG, "rt_render: rectangle [%d,%d)x[%d,%d) outside %dx%d", p->x0, p->x1, p->y0, p->y1, p->width, p->height);
     if (p->sample_count < 0 || p->sample_begin < 0 || p->max_bounces < 0 || p->max_bounces > 62)
         return fail(c, RT_ERR_INVALID_ARG, "rt_render: bad sample range or max_bounces");
-    if ((p->flags & ~(uint32_t)(RT_RENDER_WAVEFRONT | RT_RENDER_STRICT_DEPTH)) != 0 || p->wavefront_paths < 0)
+    if ((p->flags & ~(uint32_t)(RT_RENDER_WAVEFRONT | RT_RENDER_STRICT_DEPTH | RT_RENDER_NO_DEFER)) != 0 || p->wavefront_paths < 0)
         return fail(c, RT_ERR_INVALID_ARG, "rt_render: unknown flag bits 0x%x or negative wavefront_paths", p->flags);
     if ((p->flags & RT_RENDER_WAVEFRONT) && (p->flags & RT_RENDER_STRICT_DEPTH))
         return fail(c, RT_ERR_UNSUPPORTED, "rt_render: the wavefront form has no strict-depth variant");
@@ -1175,11 +1176,33 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
         A.tune[0] = num("RT_TUNE_SLICE", 8); A.tune[1] = num("RT_TUNE_MORE_BELOW", 16); A.tune[2] = num("RT_TUNE_MORE_TIMES", 1); A.tune[3] = 0;
     }
 #endif
-    if (n_chunks > 1) {
-        // grows only; a larger request first drains work that may still read the old buffer
-        size_t need = (size_t)total_jobs * 3 * sizeof(float);
-        if (need > c->partial.bytes) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, c->partial.ensure(need)); }
-        A.partial = c->partial.as<float>();
+    // The lean kernel (no double-precision settling code, five waves per SIMD) renders; the few paths it sets
+    // aside are traced again by k_aside, the jobs it gives up (no room left in the list) by the full kernel;
+    // k_reduce_chunks folds everything into the buffer.  Strict depth (every tenth ray would be set aside) and
+    // RT_RENDER_NO_DEFER go straight to the full kernel.  All on `stream`, no host synchronisation.
+    const bool strict = (p->flags & RT_RENDER_STRICT_DEPTH) != 0;
+    const bool lean = !strict && !(p->flags & RT_RENDER_NO_DEFER);
+    const unsigned long long total_paths = (unsigned long long)rect_px * (unsigned long long)p->sample_count;
+    const uint32_t aside_cap = lean ? (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(total_paths / 64, 4096), 1ull << 25) : 0;
+    {
+        // scratch grows only; a larger request first drains work that may still read the old buffers
+        const size_t need_partial = (size_t)total_jobs * 3 * sizeof(double), need_aside = (size_t)aside_cap * sizeof(AsideRec);
+        const size_t need_head = lean ? (size_t)total_jobs * sizeof(int32_t) : 0, need_dirty = lean ? (size_t)total_jobs : 0, need_list = lean ? (size_t)total_jobs * 4 : 0;
+        if (need_partial > c->partial.bytes || need_aside > c->aside.bytes || need_head > c->aside_head.bytes ||
+            need_dirty > c->dirty.bytes || need_list > c->dirty_list.bytes) {
+            HIP_TRY(c, hipDeviceSynchronize());
+            HIP_TRY(c, c->partial.ensure(need_partial)); HIP_TRY(c, c->aside.ensure(need_aside)); HIP_TRY(c, c->aside_head.ensure(need_head));
+            HIP_TRY(c, c->dirty.ensure(need_dirty)); HIP_TRY(c, c->dirty_list.ensure(need_list));
+        }
+        A.partial = c->partial.as<double>();
+        uint32_t *counters = c->job_counter.as<uint32_t>();   // [0] jobs handed out, [1] records in the list, [2] jobs given up, [3] jobs handed out again, [4] records handed out
+        if (lean) {
+            A.aside = c->aside.as<AsideRec>(); A.aside_count = counters + 1; A.aside_cap = aside_cap;
+            A.dirty_list = c->dirty_list.as<uint32_t>(); A.dirty_count = counters + 2; A.dirty = c->dirty.as<uint8_t>();
+            A.head = c->aside_head.as<int32_t>();
+            HIP_TRY(c, hipMemsetAsync(c->aside_head.p, 0xFF, need_head, stream));
+            HIP_TRY(c, hipMemsetAsync(c->dirty.p, 0, need_dirty, stream));
+        }
     }
     HIP_TRY(c, hipMemsetAsync(c->job_counter.p, 0, 256, stream));
     const long long waves_needed = (total_jobs + 63) / 64;
@@ -1190,17 +1213,26 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     if (!have_ev) { HIP_TRY(c, hipEventCreate(&ev.a)); HIP_TRY(c, hipEventCreate(&ev.b)); }
     HIP_TRY(c, hipEventRecord(ev.a, stream));
     const DevScene S = c->S;
-    const bool strict = (p->flags & RT_RENDER_STRICT_DEPTH) != 0;
     dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
-        if (strict) hipLaunchKernelGGL((k_render<decltype(T)::value, decltype(P)::value, true>), dim3(blocks), dim3(256), 0, stream, S, A);
-        else hipLaunchKernelGGL((k_render<decltype(T)::value, decltype(P)::value, false>), dim3(blocks), dim3(256), 0, stream, S, A);
+        constexpr int TRI = decltype(T)::value; constexpr bool SPH = decltype(P)::value;
+        if (strict) hipLaunchKernelGGL((k_render<TRI, SPH, true, false>), dim3(blocks), dim3(256), 0, stream, S, A);
+        else if (!lean) hipLaunchKernelGGL((k_render<TRI, SPH, false, false>), dim3(blocks), dim3(256), 0, stream, S, A);
+        else {
+            hipLaunchKernelGGL((k_render<TRI, SPH, false, true>), dim3(blocks), dim3(256), 0, stream, S, A);
+            // the paths set aside: the full kernel's job loop over the records, one path each
+            RenderArgs Q = A;
+            Q.path_mode = 1; Q.job_list_count = A.aside_count; Q.job_counter = A.job_counter + 4;
+            hipLaunchKernelGGL((k_render<TRI, SPH, false, false>), dim3(std::min(blocks, (unsigned)c->n_cu * 4)), dim3(256), 0, stream, S, Q);
+            // the jobs given up: the same job loop over the list (nearly always a short one)
+            RenderArgs R = A;
+            R.job_list = A.dirty_list; R.job_list_count = A.dirty_count; R.job_counter = A.job_counter + 3;
+            hipLaunchKernelGGL((k_render<TRI, SPH, false, false>), dim3(std::min(blocks, (unsigned)c->n_cu * 4)), dim3(256), 0, stream, S, R);
+        }
     });
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(ev.b, stream));
-    if (n_chunks > 1) {
-        hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((rect_px + 255) / 256)), dim3(256), 0, stream, A);
-        HIP_TRY(c, hipGetLastError());
-    }
+    hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((rect_px + 255) / 256)), dim3(256), 0, stream, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(ev.b, stream));   // (the timed span is everything the call launched: render, set-aside paths, jobs again, fold)
     { std::lock_guard<std::mutex> g(c->mu); c->timed.push_back(ev); c->launches++; c->paths_launched += (uint64_t)rect_px * (uint64_t)p->sample_count; }
     return RT_OK;
 }
@@ -1305,7 +1337,7 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     std::memset(out, 0, sizeof *out);
     out->rays = v[kStatRays]; out->paths = v[kStatPaths]; out->sphere_tests = v[kStatSphTests]; out->tri_tests = v[kStatTriTests];
     out->aabb_tests = 0; out->bvh_node_tests = v[kStatBvhNodes]; out->exact_rays = v[kStatExact]; out->refined_hits = v[kStatRefine];
-    out->sky_lookups = v[kStatSky]; out->shaded_hits = v[kStatShaded];
+    out->sky_lookups = v[kStatSky]; out->shaded_hits = v[kStatRays] - v[kStatSky];   // every query ends in a shaded hit or the environment
     { std::lock_guard<std::mutex> g(c->mu); out->kernel_ms = c->kernel_ms; out->launches = c->launches; out->paths += c->paths_launched;
       out->kernel_ms_min = c->kernel_ms_min; out->kernel_ms_max = c->kernel_ms_max; }
     return RT_OK;
@@ -1357,6 +1389,16 @@ extern "C" int rt_debug_uniforms(rt_ctx *c, uint32_t pixel, uint32_t sample, uin
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(out_host, b.p, (size_t)n_segments * 5 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// What the last rt_render call set aside (tests and tuning): out[0] jobs handed out, [1] paths set aside by the lean
+// kernel, [2] jobs it gave up, [3] jobs the full kernel took from that list.  Synchronises.
+extern "C" int rt_debug_render_counters(rt_ctx *c, uint32_t *out4) {
+    if (!c || !out4) return fail(c, RT_ERR_INVALID_ARG, "rt_debug_render_counters: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(out4, c->job_counter.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -1051,7 +1051,9 @@ RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename Fi
 // Everything after the first pass: judge the winner, settle what float32 could not, build the hit
 // record.  `e64`, when given, receives the double-precision record whenever the exact code produced
 // the hit (e64->hit says whether it did).
-template <int TRI, bool HAS_SPH, bool STRICT>
+constexpr int32_t kHowDeferred = 3;   // Hit::how of a query handed back unanswered (hit_finish with DEFER)
+
+template <int TRI, bool HAS_SPH, bool STRICT, bool DEFER = false>
 RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
                       BvhCounters bc, ExactHit *e64, const SpherePre *pre = nullptr) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0; h.tag = 0u; h.own_ratio = kInf;
@@ -1104,7 +1106,25 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
     PROF(kProfJudge);
     const bool settle = route != kRouteFilter || box_open || (gprim >= 0 && (status != 0 || (has_second && !(second_lo > thi))));
     ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
-    if (settle) {
+    if (DEFER) {
+        // The kernel this is compiled into holds none of the settling code: a query the float32 code cannot
+        // answer alone is handed back unanswered (how == kHowDeferred), and the caller sets the whole path aside
+        // for the kernel that does hold it.  (The settling code is 60 % of the machine code of a render kernel
+        // and a third of its vector registers: without it five waves fit a SIMD instead of four.)
+        // One case stays: a triangle that is certainly the hit but whose float32 depth is too coarse needs a single
+        // double-precision plane evaluation, which costs this kernel no registers to speak of, and half of all the
+        // queries that would be handed back are of this kind.
+        bool hand_back = settle;
+        if (settle && route == kRouteFilter && !box_open && !pair_open && gprim >= S.n_spheres && status == 1) {
+            const Ray64 x64 = ray64(r, rr);
+            t = (float)exact_tri_depth(S.cold->tri64 + 9 * (size_t)(gprim - S.n_spheres), x64.o, x64.d);
+            thi = t * (1.0f + 2.0f * kU);
+            h.refined = true; h.how = 1;
+            hand_back = has_second && !(second_lo > thi);
+        }
+        if (hand_back) { h.how = kHowDeferred; h.refined = false; return h; }
+    }
+    if (!DEFER && settle) {
         const Ray64 x64 = ray64(r, rr);
         const D3 o64 = x64.o, d64 = x64.d;
         const bool scan = route == kRouteScan;
@@ -1187,18 +1207,22 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
 }
 
 // One closest-hit query from start to end.
-template <int TRI, bool HAS_SPH, bool STRICT>
+template <int TRI, bool HAS_SPH, bool STRICT, bool DEFER = false>
 RT_DEV Hit closest_hit(SceneRef S, const Ray &r, ExactHit *e64, const RayResidue rr) {
     typename FirstPass<TRI>::type first;
     first.init(S);
     BvhCounters bc = bvh_counters();
     SpherePre pre; pre.id = -1; pre.tl = kInf; pre.v.status = 2; pre.v.root = 0; pre.v.t = 0; pre.v.thi = 0;
+    // (hierarchy scenes: no early sphere verdict - the render kernel's sliced walk carries none from trip to trip,
+    // and the kernel that traces its set-aside paths again through this function must meet the same candidates
+    // with the same bounds, so that both settle the same queries and every path comes out bit for bit the same)
+    constexpr bool kUsePre = HAS_SPH && TRI != kTriBvh;
     if (ray_route<TRI>(r) == kRouteFilter) {
-        hit_begin<TRI, HAS_SPH>(S, r, rr, first, HAS_SPH ? &pre : nullptr, STRICT ? kRelAcceptStrict : kRelAcceptRender,
+        hit_begin<TRI, HAS_SPH>(S, r, rr, first, kUsePre ? &pre : nullptr, STRICT ? kRelAcceptStrict : kRelAcceptRender,
                                 STRICT ? 0.0f : kAbsAcceptRender * (r.o2 + S.scene_radius));
         if (TRI == kTriBvh) { int node = 0; search_bvh(S, r, first, bc, node, 0x7FFFFFFF); }
     }
-    return hit_finish<TRI, HAS_SPH, STRICT>(S, r, rr, first, bc, e64, HAS_SPH ? &pre : nullptr);
+    return hit_finish<TRI, HAS_SPH, STRICT, DEFER>(S, r, rr, first, bc, e64, kUsePre ? &pre : nullptr);
 }
 
 }  // namespace rt

@@ -264,12 +264,14 @@ RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float
 }
 
 // One segment: closest hit, then environment or one bounce.
-template <int TRI, bool HAS_SPH, bool STRICT = false>
+// (DEFER: see hit_finish; a query handed back unanswered ends the path HERE with no radiance, h.how says so.)
+template <int TRI, bool HAS_SPH, bool STRICT = false, bool DEFER = false>
 RT_DEV bool path_step(SceneRef S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h,
                       uint32_t &sky_count) {
     Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio);
     PROF(kProfRaySetup);
-    h = closest_hit<TRI, HAS_SPH, STRICT>(S, ray, nullptr, path_residue(S, ray_res, p));
+    h = closest_hit<TRI, HAS_SPH, STRICT, DEFER>(S, ray, nullptr, path_residue(S, ray_res, p));
+    if (DEFER && h.how == kHowDeferred) { er = eg = eb = 0.0f; return false; }
     const bool alive = path_shade(S, p, max_bounces, h, er, eg, eb, sky_count);
     PROF(kProfBounce);
     return alive;
@@ -303,8 +305,22 @@ constexpr int kWalkSlice = 8;   // boxes a lane visits per trip of the render lo
 
 // STRICT: a float32 hit depth is accepted only under the closest-hit entry's error bound (9.5e-6
 // relative) instead of the render's looser one (see kRelAcceptRender); hit identity is the same.
-template <int TRI, bool HAS_SPH, bool STRICT>
-__global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const RenderArgs A) {
+//
+// LEAN: the kernel holds none of the double-precision settling code (hit_finish with DEFER).  A path
+// one of whose queries needs that code is SET ASIDE: the lane appends (pixel, sample, job) to
+// RenderArgs::aside, counts the sample as done with no radiance, and goes on.  The FULL kernel is then
+// launched over that list (RenderArgs::path_mode: a job is one record = one path, which goes on from the
+// state the record holds - the same ray, the same random stream - and its radiance goes into the record), and
+// k_reduce_chunks adds the records to their pixels.  When the list is full the lane gives its whole
+// JOB up instead (RenderArgs::dirty_list),
+// and a launch of the full kernel over that list (RenderArgs::job_list) renders those jobs again.  Every job's sum goes to its own slot of RenderArgs::partial in double precision: the
+// sum of a few hundred float32 terms is then (all but) exact, so a pixel's value does not depend on
+// which of its samples went which way.
+#ifndef RT_LEAN_WAVES
+#define RT_LEAN_WAVES 5   // waves per SIMD the lean kernel is compiled for (measured: see the table in the design notes)
+#endif
+template <int TRI, bool HAS_SPH, bool STRICT, bool LEAN>
+__global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const DevScene S_arg, const RenderArgs A) {
     SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     // wave-uniform job window
     uint32_t win_next = 0, win_end = 0;
@@ -313,7 +329,9 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
     bool have_job = false, in_path = false;
     uint32_t slot = 0;
     int s_cur = 0, s_end = 0;
-    float ar = 0, ag = 0, ab = 0;
+    double ar = 0, ag = 0, ab = 0;
+    uint32_t job_rays0 = 0, job_sky0 = 0;   // LEAN: this lane's counters when its job began (a job given up is not counted)
+    int32_t job_last_rec = -1;              // LEAN: the record of the path this lane's job set aside last (-1: none yet)
     Path p;
     p.ox = p.oy = p.oz = 0; p.dx = p.dy = 0; p.dz = 1; p.tr = p.tg = p.tb = 1; p.key0 = p.key1 = 0;
     p.depth = 0; p.origin = -1; p.tag = 0u; p.own_ratio = kInf; p.inside = false; p.pixel = 0;
@@ -365,16 +383,33 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
         while (idle != 0 && !(drained && win_next == win_end)) {
             if (win_next == win_end) {
                 uint32_t base = 0;
-                if (lane_id() == 0) base = atomicAdd(JOB(job_counter), (uint32_t)kJobBlock);
+                // (a job list is short - thousands of jobs, not millions: windows of one job per lane spread it over the chip)
+                const uint32_t window = JOB(job_list_count) != nullptr ? 64u : (uint32_t)kJobBlock;
+                if (lane_id() == 0) base = atomicAdd(JOB(job_counter), window);
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= JOB(total_jobs)) { drained = true; break; }
+                uint32_t n_jobs = JOB(job_list_count) != nullptr ? *JOB(job_list_count) : JOB(total_jobs);
+                if (!LEAN && JOB(path_mode) && n_jobs > JOB(aside_cap)) n_jobs = JOB(aside_cap);
+                if (base >= n_jobs) { drained = true; break; }
                 win_next = base;
-                win_end = base + kJobBlock < JOB(total_jobs) ? base + kJobBlock : JOB(total_jobs);
+                win_end = base + window < n_jobs ? base + window : n_jobs;
             }
             uint32_t avail = win_end - win_next;
             uint32_t r = rank_in(idle);
             if (!have_job && r < avail) {
                 uint32_t job = win_next + r;
+                if (!LEAN && JOB(path_mode)) {
+                    // one record = one path: it goes on from the query the lean kernel handed back, result into the record
+                    const AsideRec rec = JOB(aside)[job];
+                    slot = job; s_cur = (int)rec.sample; s_end = s_cur + 1;
+                    p.pixel = rec.pixel; p.key0 = rec.pixel ^ A.seed_lo; p.key1 = rec.sample ^ A.seed_hi;
+                    p.ox = rec.ox; p.oy = rec.oy; p.oz = rec.oz; p.dx = rec.dx; p.dy = rec.dy; p.dz = rec.dz;
+                    p.tr = rec.tr; p.tg = rec.tg; p.tb = rec.tb; p.depth = (int32_t)rec.depth; p.origin = rec.origin;
+                    p.tag = rec.tag; p.own_ratio = rec.own_ratio; p.inside = rec.inside != 0u;
+                    ar = ag = ab = 0.0;
+                    in_path = true; walking = false;
+                    have_job = !JOB(dirty)[rec.slot];   // (its job was given up later on: the job list covers it)
+                } else {
+                if (JOB(job_list) != nullptr) job = JOB(job_list)[job];
                 const uint32_t rect_px = (uint32_t)(JOB(rect_w) * JOB(rect_h));
                 const FastDiv div_px = {JOB(div_rect_px.d), JOB(div_rect_px.m), JOB(div_rect_px.sh1), JOB(div_rect_px.sh2)};
                 const FastDiv div_h = {JOB(div_rect_h.d), JOB(div_rect_h.m), JOB(div_rect_h.sh1), JOB(div_rect_h.sh2)};
@@ -387,8 +422,10 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                 s_cur = sample_begin + (int)chunk * chunk_samples;
                 int lim = sample_begin + JOB(sample_count);
                 s_end = s_cur + chunk_samples < lim ? s_cur + chunk_samples : lim;
-                ar = ag = ab = 0.0f;
+                ar = ag = ab = 0.0;
+                job_rays0 = l_rays; job_sky0 = l_sky; job_last_rec = -1;
                 have_job = true; in_path = false;
+                }
             }
             uint32_t want = (uint32_t)__builtin_popcountll(idle);
             win_next += want < avail ? want : avail;
@@ -427,7 +464,9 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
 #ifdef RT_TUNE
                 const int walk_slice = A.tune[0], more_below = A.tune[1], more_times = A.tune[2];
 #else
-                constexpr int walk_slice = kWalkSlice, more_below = 16, more_times = 1;
+                // (path mode: every lane holds a path that went deep or grazed something - longer slices, fewer trips)
+                const int walk_slice = (!LEAN && JOB(path_mode)) ? 4 * kWalkSlice : kWalkSlice;
+                constexpr int more_below = 16, more_times = 1;
 #endif
                 if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
                 // When only a few lanes are through, closing their queries now would run ~1,000
@@ -440,29 +479,32 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
                 if (walk_node < 0) {
                     walking = false;
                     BvhCounters second_pass = bc; second_pass.nodes = 0; second_pass.tris = 0;
-                    h = hit_finish<TRI, HAS_SPH, STRICT>(S, ray, rr, first, second_pass, nullptr);
+                    h = hit_finish<TRI, HAS_SPH, STRICT, LEAN>(S, ray, rr, first, second_pass, nullptr);
                     bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
-                    alive = path_shade(S, p, A.max_bounces, h, er, eg, eb, l_sky);
+                    if (LEAN && h.how == kHowDeferred) alive = false;
+                    else alive = path_shade(S, p, A.max_bounces, h, er, eg, eb, l_sky);
                     PROF(kProfBounce);
                     l_rays += 1u;
-                    rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0);
+                    rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0) | (LEAN && h.how == kHowDeferred ? 4 : 0);
                 }
             } else {
                 l_rays += 1u;
-                alive = path_step<TRI, HAS_SPH, STRICT>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h, l_sky);
-                rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0);
+                alive = path_step<TRI, HAS_SPH, STRICT, LEAN>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h, l_sky);
+                rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0) | (LEAN && h.how == kHowDeferred ? 4 : 0);
             }
             if (!alive) {
-                ar = fma_(p.tr, er, ar); ag = fma_(p.tg, eg, ag); ab = fma_(p.tb, eb, ab);
+                // (products in float32 as ever; the SUM in double precision: see the note on LEAN above)
+                ar += (double)(p.tr * er); ag += (double)(p.tg * eg); ab += (double)(p.tb * eb);
                 in_path = false;
                 s_cur++;
                 if (s_cur >= s_end) {
-                    if (JOB(n_chunks) > 1) {
-                        float *dst = JOB(partial) + 3 * (size_t)slot;
-                        dst[0] = ar; dst[1] = ag; dst[2] = ab;
+                    if (!LEAN && JOB(path_mode)) {
+                        AsideRec *rec = JOB(aside) + slot;
+                        rec->r = (float)ar; rec->g = (float)ag; rec->b = (float)ab;   // (one product each: exact)
+                        l_rays -= 1u;                                                // (the query handed back was counted by the lean kernel)
                     } else {
-                        float *dst = JOB(accum) + 3 * (size_t)p.pixel;
-                        dst[0] += ar; dst[1] += ag; dst[2] += ab;
+                        double *dst = JOB(partial) + 3 * (size_t)slot;
+                        dst[0] = ar; dst[1] = ag; dst[2] = ab;
                     }
                     have_job = false;
                 }
@@ -472,6 +514,40 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
         if (__ballot(rare != 0) != 0) {
             w_exact += (uint32_t)__builtin_popcountll(__ballot((rare & 1) != 0));
             w_refine += (uint32_t)__builtin_popcountll(__ballot((rare & 2) != 0));
+            if (LEAN) {
+                // paths set aside this trip: one counter bump for the wave, one record per path.  (s_cur has moved
+                // on: the path is sample s_cur - 1 of job `slot`; p.depth is still the segment that was handed back.)
+                // The records of one job form a list in the order the job's lane set them aside - descending sample
+                // index from RenderArgs::head - so the fold adds them in an order that does not depend on where in the
+                // list array they landed.
+                const bool want = (rare & 4) != 0;
+                const unsigned long long dm = __ballot(want);
+                if (dm != 0) {
+                    uint32_t base = 0;
+                    if (lane_id() == (uint32_t)__builtin_ctzll(dm)) base = atomicAdd(JOB(aside_count), (uint32_t)__builtin_popcountll(dm));
+                    base = (uint32_t)__shfl((int)base, __builtin_ctzll(dm), 64);
+                    if (want) {
+                        const uint32_t idx = base + rank_in(dm);
+                        if (idx < JOB(aside_cap)) {
+                            AsideRec rec;
+                            rec.pixel = p.pixel; rec.sample = (uint32_t)(s_cur - 1); rec.slot = slot; rec.next = job_last_rec;
+                            rec.r = rec.g = rec.b = 0.0f; rec.depth = (uint32_t)p.depth;
+                            rec.ox = p.ox; rec.oy = p.oy; rec.oz = p.oz; rec.dx = p.dx; rec.dy = p.dy; rec.dz = p.dz;
+                            rec.tr = p.tr; rec.tg = p.tg; rec.tb = p.tb; rec.origin = p.origin; rec.tag = p.tag;
+                            rec.own_ratio = p.own_ratio; rec.inside = p.inside ? 1u : 0u; rec.pad[0] = rec.pad[1] = rec.pad[2] = 0u;
+                            JOB(aside)[idx] = rec;
+                            JOB(head)[slot] = (int32_t)idx;
+                            job_last_rec = (int32_t)idx;
+                        } else {
+                            // no room in the list: this lane's whole job is rendered again by the full kernel; nothing of it counts here
+                            JOB(dirty)[slot] = 1;
+                            JOB(dirty_list)[atomicAdd(JOB(dirty_count), 1u)] = slot;
+                            l_rays = job_rays0; l_sky = job_sky0;
+                            have_job = false;
+                        }
+                    }
+                }
+            }
         }
         PROF(kProfStats);
     }
@@ -500,19 +576,28 @@ __global__ __launch_bounds__(256, 4) void k_render(const DevScene S_arg, const R
 }
 #undef JOB
 
-// Folds the chunk slots of a render call into the accumulation buffer, in chunk order.
+// Folds a render call into the accumulation buffer: per pixel of the rectangle the job sums of its chunks, in
+// chunk order, each followed by the paths of that job that were set aside (its AsideRec list, latest sample first) - all in
+// double precision, rounded to float32 once.  Records of a job that was given up and rendered again
+// (RenderArgs::dirty) are skipped: that job's slot already holds all of its samples.
 __global__ __launch_bounds__(256) void k_reduce_chunks(const RenderArgs A) {
     const uint32_t rect_px = (uint32_t)(A.rect_w * A.rect_h);
     uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
     if (pl >= rect_px) return;
     int px = A.x0 + (int)(pl / (uint32_t)A.rect_h), py = A.y0 + (int)(pl % (uint32_t)A.rect_h);
-    float r = 0, g = 0, b = 0;
+    double r = 0, g = 0, b = 0;
     for (int c = 0; c < A.n_chunks; ++c) {
-        const float *src = A.partial + 3 * ((size_t)c * rect_px + pl);
+        const double *src = A.partial + 3 * ((size_t)c * rect_px + pl);
         r += src[0]; g += src[1]; b += src[2];
     }
+    for (int c = 0; A.head != nullptr && c < A.n_chunks; ++c) {
+        const size_t slot = (size_t)c * rect_px + pl;
+        const int first = A.head[slot];
+        if (first < 0 || A.dirty[slot]) continue;
+        for (int i = first; i >= 0; i = A.aside[i].next) { r += (double)A.aside[i].r; g += (double)A.aside[i].g; b += (double)A.aside[i].b; }
+    }
     float *dst = A.accum + 3 * ((size_t)px * A.height + py);
-    dst[0] += r; dst[1] += g; dst[2] += b;
+    dst[0] += (float)r; dst[1] += (float)g; dst[2] += (float)b;
 }
 
 // Diagnostic / parity kernel: one thread traces one whole path and records every segment.

@@ -180,6 +180,25 @@ __device__ __forceinline__ ScenePtr kernarg_scene() { return (ScenePtr)__builtin
 // the constants, the device spends a multiply-high and two shifts instead of a ~30-instruction divide.
 struct FastDiv { uint32_t d, m, sh1, sh2; };
 
+// A path the lean render kernel could not finish (one of its closest-hit queries needs the double-precision
+// settling code, which that kernel does not hold): the state of the path in front of that query, so that the
+// full kernel can go on from there, and - filled in by the full kernel - what the path contributes.  96 bytes.
+struct AsideRec {
+    uint32_t pixel, sample;   // the path: x * H + y, global sample index (they key its random stream)
+    uint32_t slot;            // the job (pixel of the rectangle, chunk of samples) the path belongs to
+    int32_t next;             // the record the same job set aside before this one (list from RenderArgs::head), -1 = none
+    float r, g, b;            // the path's radiance (throughput x terminal radiance): written by the full kernel
+    uint32_t depth;           // index of the path segment whose query was handed back
+    float ox, oy, oz, dx, dy, dz;   // that segment's ray
+    float tr, tg, tb;         // throughput in front of it
+    int32_t origin;           // primitive the ray starts on, -1 = camera
+    uint32_t tag;             // TriAux::tag of that primitive
+    float own_ratio;          // Hit::own_ratio of the hit the ray leaves from
+    uint32_t inside;          // Ray.inside
+    uint32_t pad[3];
+};
+static_assert(sizeof(AsideRec) == 96, "AsideRec: six 16-byte loads");
+
 struct RenderArgs {
     int32_t width, height, x0, y0, rect_w, rect_h;
     // Camera-ray table built by k_raygen for this (camera, width, height): per pixel (x * height + y)
@@ -192,7 +211,13 @@ struct RenderArgs {
     FastDiv div_rect_px, div_rect_h;   // job -> (chunk, pixel in rectangle) -> (x, y)
     uint32_t *job_counter;    // device word, zero at launch
     float *accum;             // (W,H,3) running sum
-    float *partial;           // [n_chunks][rect_w*rect_h][3] when n_chunks > 1, else unused
+    double *partial;          // [n_chunks][rect_w*rect_h][3]: every job's sum over its samples
+    // paths set aside by the lean kernel, and jobs it gave up (no room left in the list): see k_render
+    AsideRec *aside; uint32_t *aside_count; uint32_t aside_cap;
+    uint32_t *dirty_list, *dirty_count; uint8_t *dirty;   // [total_jobs] job ids, their number, one byte per job
+    int32_t *head;            // [total_jobs] the record each job set aside last, -1 = none
+    const uint32_t *job_list, *job_list_count;   // when set: the jobs to run are job_list[0, *job_list_count) instead of [0, total_jobs)
+    int32_t path_mode;        // full kernel only: the jobs are the records aside[0, min(*job_list_count, aside_cap)), one path each
     unsigned long long *stats;  // kStat* counters
     unsigned long long *prof;   // section-timer totals (diagnostic builds with RT_SECTION_TIMERS), else null
 #ifdef RT_TUNE

@@ -300,9 +300,10 @@ def test_wavefront_form_traces_the_same_paths(backend, monkeypatch):
         assert sa[k] == sw[k], (k, sa[k], sw[k])
     # how many boxes and leaf triangles a walk tests depends a little on where its slices end (a leaf
     # met at the end of a slice is tested before or after the boxes that follow it, which moves the
-    # pruning bound): the two forms cut their walks differently
+    # pruning bound): the two forms cut their walks differently; and the default form walks the query of a path it
+    # sets aside twice (once in the lean kernel, once in the full one)
     for k in ("tri_tests", "bvh_node_tests"):
-        assert abs(sa[k] - sw[k]) <= 0.01 * sa[k], (k, sa[k], sw[k])
+        assert abs(sa[k] - sw[k]) <= 0.02 * sa[k], (k, sa[k], sw[k])
 
 
 def test_refit_for_moved_mesh_equals_rebuild(backend):
