@@ -1211,25 +1211,26 @@ def test_library_merge_one_rank(backend):
 
 @pytest.mark.parametrize("scene,W,H,spp", [("room", 96, 54, 16), ("room", 48, 27, 64), ("random_spheres_seed7", 160, 90, 8),
                                            ("room_horse", 96, 54, 8), ("room_horse", 48, 27, 128)])
-def test_lean_kernel_with_set_aside_paths_equals_full_kernel(backend, scene, W, H, spp):
+@pytest.mark.parametrize("strict", [False, True])
+def test_lean_kernel_with_set_aside_paths_equals_full_kernel(backend, scene, W, H, spp, strict):
     """rt_render runs a lean kernel without the double-precision settling code: paths that need it are
     set aside, traced again by a second kernel with the full code and folded in; a job whose paths
     find no room in the list is rendered again by the full kernel (the 48x27 case: a list of 4,096
     records for 82,944 paths of which the image diagonals send a tenth aside).  Job sums are kept in
     double precision, so the image must equal the full kernel's (RT_RENDER_NO_DEFER) bit for bit, in
-    whole-image calls and in tiles, and the statistics must agree."""
+    whole-image calls and in tiles, and the statistics must agree (strict depth: both flags take the full kernel)."""
     _set(backend, scene)
     out = {}
     for no_defer in (True, False):
         backend.resize(W, H)
         backend.reset_stats()
-        backend.render(W, H, 0, spp, 8, h.SEED_RENDER, no_defer=no_defer)
+        backend.render(W, H, 0, spp, 8, h.SEED_RENDER, no_defer=no_defer, strict_depth=strict)
         backend.synchronize()
         img = backend.read().copy()
         st = backend.stats()
         backend.resize(W, H)
         for rect in ((0, W // 2, 0, H), (W // 2, W, 0, H // 3), (W // 2, W, H // 3, H)):
-            backend.render(W, H, 0, spp, 8, h.SEED_RENDER, rect=rect, no_defer=no_defer)
+            backend.render(W, H, 0, spp, 8, h.SEED_RENDER, rect=rect, no_defer=no_defer, strict_depth=strict)
         backend.synchronize()
         out[no_defer] = (img, st, backend.read().copy())
     full, lean = out[True], out[False]
