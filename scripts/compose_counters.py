@@ -1,7 +1,7 @@
 """Turn the passes of scripts/collect_profiles.sh into the counter files bench.py reads (developer tool):
     python scripts/compose_counters.py <tag>      -> profiles/r2_room_counters.json, profiles/r2_bvh_counters.json,
                                                      profiles/r2_bench_kernel_stats.csv
-Counters are summed over the chip for the LAST k_render launch of each profiled script (the one after the warm-up)."""
+Counters are summed over the chip and over all kernels of the one rt_render call each profiled script makes."""
 import csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1]
@@ -9,16 +9,13 @@ root = f"gpurun_out/prof_{tag}"
 
 
 def counters(name):
-    """{counter: value} of the last k_render dispatch in pass `name`."""
+    """{counter: value} summed over every k_render dispatch of pass `name` (one rt_render call: the lean kernel,
+    the full kernel over the set-aside paths and over the given-up jobs) plus the fold kernel."""
     files = glob.glob(f"{root}/{name}/**/*counter_collection.csv", recursive=True)
-    rows = [r for f in files for r in csv.DictReader(open(f)) if "k_render" in r["Kernel_Name"]]
-    if not rows:
-        return {}
-    last = max(int(r["Dispatch_Id"]) for r in rows)
+    rows = [r for f in files for r in csv.DictReader(open(f)) if "k_render" in r["Kernel_Name"] or "k_reduce_chunks" in r["Kernel_Name"]]
     out = {}
     for r in rows:
-        if int(r["Dispatch_Id"]) == last:
-            out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     return out
 
 
@@ -59,7 +56,7 @@ def compose(prefix, workload, kernel, rays_pattern):
     d["kernel_ms (under the counters)"] = kernel_ms
     out = {"workload": workload, "kernel": kernel,
            "collected": "rocprofv3 --pmc, one run per pass (FETCH_SIZE; WRITE_SIZE; two or three passes of SQ counters; cache counters), "
-                        "gfx950, scripts/collect_profiles.sh; the launch after the warm-up launch",
+                        "gfx950, scripts/collect_profiles.sh; summed over every kernel of the one rt_render call (lean kernel, full kernel over set-aside paths and given-up jobs, fold)",
            "counters": c, "derived": d}
     out.update({k: d[k] for k in ("hbm_bytes_per_ray", "executed_fp32_flops_per_ray", "active_lanes_per_valu_instruction") if k in d})
     return out
@@ -67,10 +64,10 @@ def compose(prefix, workload, kernel, rays_pattern):
 
 os.makedirs("profiles", exist_ok=True)
 room = compose("room", "scripts/prof_room.py room 256: room 1920x1080, 256 spp, 8 bounces (bench.py's launch), one launch",
-               "rt::k_render<1,true,false>", r"kernel ([0-9.]+) ms rays ([0-9]+)")
+               "rt::k_render<1,true,false,true> (+ full kernel passes, fold)", r"kernel ([0-9.]+) ms rays ([0-9]+)")
 json.dump(room, open("profiles/r2_room_counters.json", "w"), indent=1)
 bvh = compose("bvh", "scripts/prof_bvh.py 6 16: room + 1.18 M-triangle mesh (BASELINE config C4's scene), 1920x1080, 16 spp, 8 bounces, one launch",
-              "rt::k_render<2,true,false>", r"kernel ([0-9.]+) ms rays ([0-9]+)")
+              "rt::k_render<2,true,false,true> (+ full kernel passes, fold)", r"kernel ([0-9.]+) ms rays ([0-9]+)")
 json.dump(bvh, open("profiles/r2_bvh_counters.json", "w"), indent=1)
 for f in glob.glob(f"{root}/stats/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, "profiles/r2_bench_kernel_stats.csv")

@@ -15,4 +15,4 @@ be.resize(W, H)
 be.render(W, H, 0, spp, 8, 1); be.synchronize()
 st = be.stats()
 print(f"tris {sc.n_tris} kernel {st['kernel_ms']:.2f} ms rays {st['rays']} nodes/ray {st['bvh_node_tests']/st['rays']:.1f} tris/ray {st['tri_tests']/st['rays']:.1f}")
-print('set aside:', be.render_counters())
+print("set aside:", be.render_counters())

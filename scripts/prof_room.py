@@ -13,4 +13,4 @@ be.resize(W, H)
 be.render(W, H, 0, spp, 8, 1); be.synchronize()
 st = be.stats()
 print(f"{name} kernel {st['kernel_ms']:.2f} ms rays {st['rays']} paths {st['paths']}")
-print('set aside:', be.render_counters())
+print("set aside:", be.render_counters())
