@@ -238,7 +238,9 @@ int rt_accum_read(rt_ctx *ctx, float *host_w_h_3);      /* blocking copy of the 
  * = Camera.get_ray (camera.py:39-50) + Renderer.raytrace (renderer.py:21-79) + environment lookup
  * (scenes/room.py:15-22) + RenderResult.add_to_px (render_result.py:24-27), for every pixel of the
  * rectangle.  Adds into `accum_dev` (device, float32 (W,H,3)); NULL = the context's own buffer.
- * Asynchronous on `stream`; rt_synchronize waits. */
+ * Asynchronous on `stream`; rt_synchronize waits.  One call enqueues several kernels (see
+ * RT_RENDER_NO_DEFER) that share context-owned scratch memory and counters: calls on one context go to
+ * ONE stream, or are ordered by the caller (events) if they use several; contexts are independent. */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, float *accum_dev, void *stream);
 int rt_synchronize(rt_ctx *ctx, void *stream);
 

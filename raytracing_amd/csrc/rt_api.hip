@@ -1167,7 +1167,7 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     A.total_jobs = (uint32_t)total_jobs;
     A.div_rect_px = make_fast_div((uint32_t)rect_px); A.div_rect_h = make_fast_div((uint32_t)A.rect_h); A.job_counter = c->job_counter.as<uint32_t>(); A.accum = accum;
     A.stats = c->stats.as<unsigned long long>();
-#ifdef RT_SECTION_TIMERS
+#if defined(RT_SECTION_TIMERS) || defined(RT_ASIDE_REASONS)
     A.prof = A.stats + kStatCount;
 #endif
 #ifdef RT_TUNE
@@ -1342,8 +1342,9 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     return RT_OK;
 }
 
-#ifdef RT_SECTION_TIMERS
-// Diagnostic builds only: wave cycles charged to each section of the render loop since rt_reset_stats.
+#if defined(RT_SECTION_TIMERS) || defined(RT_ASIDE_REASONS)
+// Diagnostic builds only: wave cycles charged to each section of the render loop since rt_reset_stats
+// (RT_ASIDE_REASONS builds: slots 0-6 count the paths set aside by reason instead).
 int rt_debug_section_cycles(rt_ctx *c, unsigned long long *out, int n) {
     if (!c || !out) return RT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));

@@ -1112,8 +1112,9 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         // for the kernel that does hold it.  (The settling code is 60 % of the machine code of a render kernel
         // and a third of its vector registers: without it five waves fit a SIMD instead of four.)
         // One case stays: a triangle that is certainly the hit but whose float32 depth is too coarse needs a single
-        // double-precision plane evaluation, which costs this kernel no registers to speak of, and half of all the
-        // queries that would be handed back are of this kind.
+        // double-precision plane evaluation, which costs this kernel no registers to speak of.  (The sphere in the
+        // same position - 47 % of the room's hand-backs - was tried inline too: half as many paths set aside, but the
+        // double-precision sphere code slows the lean kernel by as much as the full kernel saves.)
         bool hand_back = settle;
         if (settle && route == kRouteFilter && !box_open && !pair_open && gprim >= S.n_spheres && status == 1) {
             const Ray64 x64 = ray64(r, rr);
@@ -1122,7 +1123,13 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
             h.refined = true; h.how = 1;
             hand_back = has_second && !(second_lo > thi);
         }
-        if (hand_back) { h.how = kHowDeferred; h.refined = false; return h; }
+        if (hand_back) {
+            h.how = kHowDeferred; h.refined = false;
+#ifdef RT_ASIDE_REASONS   // diagnostic builds: why (Hit::prim is free in a query handed back)
+            h.prim = route != kRouteFilter ? 0 : (box_open ? 1 : (pair_open ? 2 : (status == 2 ? 3 : (status == 1 ? (gprim < S.n_spheres ? 4 : 5) : 6))));
+#endif
+            return h;
+        }
     }
     if (!DEFER && settle) {
         const Ray64 x64 = ray64(r, rr);

@@ -486,11 +486,17 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
                     PROF(kProfBounce);
                     l_rays += 1u;
                     rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0) | (LEAN && h.how == kHowDeferred ? 4 : 0);
+#ifdef RT_ASIDE_REASONS
+                    if (LEAN && h.how == kHowDeferred) rare |= (h.prim & 7) << 4;
+#endif
                 }
             } else {
                 l_rays += 1u;
                 alive = path_step<TRI, HAS_SPH, STRICT, LEAN>(S, A.ray_res, p, A.max_bounces, er, eg, eb, h, l_sky);
                 rare = (h.how == 2 ? 1 : 0) | (h.refined ? 2 : 0) | (LEAN && h.how == kHowDeferred ? 4 : 0);
+#ifdef RT_ASIDE_REASONS
+                if (LEAN && h.how == kHowDeferred) rare |= (h.prim & 7) << 4;
+#endif
             }
             if (!alive) {
                 // (products in float32 as ever; the SUM in double precision: see the note on LEAN above)
@@ -521,6 +527,9 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
                 // index from RenderArgs::head - so the fold adds them in an order that does not depend on where in the
                 // list array they landed.
                 const bool want = (rare & 4) != 0;
+#ifdef RT_ASIDE_REASONS   // diagnostic builds: a histogram of the reasons in the section-timer slots
+                if (want && A.prof != nullptr) atomicAdd(A.prof + ((rare >> 4) & 7), 1ull);
+#endif
                 const unsigned long long dm = __ballot(want);
                 if (dm != 0) {
                     uint32_t base = 0;
