@@ -1228,6 +1228,10 @@ def test_lean_kernel_with_set_aside_paths_equals_full_kernel(backend, scene, W, 
         backend.synchronize()
         img = backend.read().copy()
         st = backend.stats()
+        if not no_defer and not strict:
+            # the roads the docstring names were really taken: paths set aside, and at 48x27 jobs given up for want of room
+            cnt = backend.render_counters()
+            assert cnt["paths_set_aside"] > 0 and (cnt["jobs_given_up"] > 0) == (W == 48), cnt
         backend.resize(W, H)
         for rect in ((0, W // 2, 0, H), (W // 2, W, 0, H // 3), (W // 2, W, H // 3, H)):
             backend.render(W, H, 0, spp, 8, h.SEED_RENDER, rect=rect, no_defer=no_defer, strict_depth=strict)
