@@ -812,6 +812,12 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             std::vector<rt_bvh_node> one, dev;
             bvh::rethread(bvh_nodes, oct, one);
             tops[oct] = bvh::reorder_top_first(one, kTopNodes, dev);
+            // what the walk reads per node: the planes this octant's rays enter through in `lo`, those they leave
+            // through in `hi`; an inner node's first child always spelled out (-(child + 2))
+            for (size_t i = 0; i < dev.size(); ++i) {
+                for (int k = 0; k < 3; ++k) if ((oct >> k) & 1) std::swap(dev[i].lo[k], dev[i].hi[k]);
+                if (dev[i].tri_begin_count == -1) dev[i].tri_begin_count = -((int32_t)i + 1 + 2);
+            }
             std::copy(dev.begin(), dev.end(), all.begin() + (size_t)oct * bvh_nodes.size());
         };
         if (bvh_nodes.size() >= 65536) {

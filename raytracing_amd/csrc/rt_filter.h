@@ -26,18 +26,30 @@ namespace rt {
 // render kernel adds the per-wave totals to a global array at its end.  In ordinary builds PROF
 // compiles to nothing and no LDS is declared.
 enum { kProfHandout = 0, kProfBegin, kProfRaySetup, kProfSpheres, kProfBigSpheres, kProfQuadRows, kProfSlabRows, kProfTriRows,
-       kProfJudge, kProfSettle, kProfRecord, kProfSky, kProfDraws, kProfBounce, kProfAccum, kProfStats, kProfWalk, kProfLeaves, kProfCount };
+       kProfJudge, kProfSettle, kProfRecord, kProfSky, kProfDraws, kProfBounce, kProfAccum, kProfStats, kProfWalk, kProfLeaves, kProfTrips, kProfLanesJob, kProfLanesStart, kProfLanesEnd,
+       kProfWalkIters, kProfWalkLanes, kProfLeafIters, kProfLeafLanes, kProfCount };
 #ifdef RT_SECTION_TIMERS
 __shared__ unsigned g_prof_acc[4][kProfCount];
 __shared__ unsigned g_prof_last[4];
 __device__ __noinline__ void prof_stamp_(int k) {
     const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { g_prof_acc[w][k] += t - g_prof_last[w]; g_prof_last[w] = t; }
+    // (the first ACTIVE lane keeps the books: a stamp inside a branch that lane 0 did not take still counts)
+    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) {
+        g_prof_acc[w][k] += t - g_prof_last[w]; g_prof_last[w] = t;
+        if (k == kProfHandout) g_prof_acc[w][kProfTrips] += 1u;   // (a count, not a time: trips of the render loop)
+    }
+}
+// a count, not a time: the number of lanes for which `yes` holds is added to slot k
+__device__ __noinline__ void prof_lanes_(int k, bool yes) {
+    const unsigned n = (unsigned)__builtin_popcountll(__ballot(yes));
+    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) g_prof_acc[threadIdx.x >> 6][k] += n;
 }
 #define PROF(k) prof_stamp_(k)
+#define PROF_LANES(k, yes) prof_lanes_(k, yes)
 #else
 #define PROF(k) ((void)0)
+#define PROF_LANES(k, yes) ((void)0)
 #endif
 
 RT_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
@@ -689,10 +701,18 @@ RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
 // at most 5 u |plane - o| <= 5 u (S + |o|) (S = scene radius); rounding the ray origin, the stored
 // planes and o +- pad adds less than 3 u (S + |o|).  So every box is widened per ray by
 // pad = 10 u (S + |o|) - folded into the origin, at no cost per node - and plain comparisons can
-// then never drop a box the exact ray touches.  A NaN slab value (0 x inf: origin exactly on a box plane, direction component zero) drops out of
+// then never drop a box the exact ray touches.  (The same bound holds for the multiply-add form used
+// below, plane * (1 / d) - (o +- pad) * (1 / d): the reciprocal's error is common to both terms and the
+// two roundings of the second term move the origin by less than 2 u |o|.)  A direction component of
+// zero makes both terms infinite: the value is the right infinity when they agree in sign and NaN when
+// they do not - that slab is then unconstrained, which only costs visits.  A NaN slab value (0 x inf: origin exactly on a box plane, direction component zero) drops out of
 // min/max and leaves that slab unconstrained.  A box is skipped when the ray misses it or enters it
 // beyond the sink's bound.
 typedef const f4 __attribute__((address_space(3))) *lds_f4_ptr;
+#ifndef RT_WALK_FLAT
+#define RT_WALK_FLAT 1   // 1: one load through a generic pointer (LDS or memory) per node; 0: a branch with a load on either
+                         // side; 2: memory only.  Measured at 1.18 M triangles, 32 samples per pixel: 46.5 / 48.3 / 46.7 ms
+#endif
 
 // Per-query walk context: test counters, and where the top levels of the hierarchy sit in LDS (if the
 // kernel staged them: n_top = 0 reads every node from memory).
@@ -712,10 +732,16 @@ template <class Sink>
 RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, int &node, int budget) {
     const float ix = rcp_(r.dx), iy = rcp_(r.dy), iz = rcp_(r.dz);
     const float pad = 10.0f * kU * (r.o2 + S.scene_radius);
-    const float oxp = r.ox + pad, oyp = r.oy + pad, ozp = r.oz + pad;   // subtracted from the low planes
-    const float oxm = r.ox - pad, oym = r.oy - pad, ozm = r.oz - pad;   // subtracted from the high planes
-    // the threading for this ray's octant: children nearer along the ray come first
-    const int oct = (r.dx < 0.0f ? 1 : 0) | (r.dy < 0.0f ? 2 : 0) | (r.dz < 0.0f ? 4 : 0);
+    // the threading for this ray's octant: children nearer along the ray come first, and every node of
+    // that copy holds the planes the ray ENTERS through in its first half, the planes it leaves through
+    // in its second - no min / max per axis
+    const bool bx = r.dx < 0.0f, by = r.dy < 0.0f, bz = r.dz < 0.0f;
+    const int oct = (bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0);
+    // entry = plane * (1 / d) + k, one multiply-add per plane; the widening sits in k: the entry value is
+    // computed from an origin moved forward along the axis by `pad`, the exit value from one moved back
+    const float sx = bx ? -pad : pad, sy = by ? -pad : pad, sz = bz ? -pad : pad;
+    const float knx = -(r.ox + sx) * ix, kny = -(r.oy + sy) * iy, knz = -(r.oz + sz) * iz;
+    const float kfx = -(r.ox - sx) * ix, kfy = -(r.oy - sy) * iy, kfz = -(r.oz - sz) * iz;
     const f4 *nodes = (const f4 *)(S.bvh_nodes + (size_t)oct * (size_t)S.n_bvh_nodes);
     const lds_f4_ptr top = bc.top + 2 * kTopNodes * oct;
     const TriRow *rows = S.leaf_rows;
@@ -731,35 +757,48 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
     constexpr int kSubSlice = 8;
     while (visited < budget && node >= 0) {
         const int stop = visited + kSubSlice < budget ? visited + kSubSlice : budget;
+        const int visited0 = visited;
         int32_t leaf = -1, leaf2 = -1;
-        while (node >= 0 && visited < stop) {
+        bool open = true;   // false: the lane stands before a third leaf (met again, and counted, next time round)
+        // The body is written without branches (selects only): as nested ifs it compiled to some forty
+        // scalar mask and branch instructions per box, more than the box test itself.
+        while (open && node >= 0 && visited < stop) {
+            PROF_LANES(kProfWalkIters, (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))); PROF_LANES(kProfWalkLanes, true);
+#if RT_WALK_FLAT == 2
+            const f4 *q = nodes + 2 * (size_t)node;
+            const f4 a = q[0], b = q[1];
+#elif RT_WALK_FLAT
+            // top levels from LDS, the rest from memory, through ONE load: the pointer says which
+            const f4 *q = node < bc.n_top ? (const f4 *)(top + 2 * node) : nodes + 2 * (size_t)node;
+            const f4 a = q[0], b = q[1];
+#else
             f4 a, b;
             if (node < bc.n_top) { a = top[2 * node]; b = top[2 * node + 1]; }                // top levels: LDS
             else { a = nodes[2 * (size_t)node]; b = nodes[2 * (size_t)node + 1]; }
-            const float skip_bits = a.w, leaf_bits = b.w;
-            const int32_t skip = (int32_t)f2u(skip_bits), info = (int32_t)f2u(leaf_bits);
-            const float x0 = (a.x - oxp) * ix, x1 = (b.x - oxm) * ix;
-            const float y0 = (a.y - oyp) * iy, y1 = (b.y - oym) * iy;
-            const float z0 = (a.z - ozp) * iz, z1 = (b.z - ozm) * iz;
-            const float tn = max_(max_(min_(x0, x1), min_(y0, y1)), max_(min_(z0, z1), 0.0f));
-            const float tf = min_(min_(max_(x0, x1), max_(y0, y1)), min_(max_(z0, z1), sink.prune_bound()));
+#endif
+            const int32_t skip = (int32_t)f2u(a.w), info = (int32_t)f2u(b.w);
+            const float x0 = fma_(a.x, ix, knx), y0 = fma_(a.y, iy, kny), z0 = fma_(a.z, iz, knz);
+            const float x1 = fma_(b.x, ix, kfx), y1 = fma_(b.y, iy, kfy), z1 = fma_(b.z, iz, kfz);
+            const float tn = max_(max_(x0, y0), max_(z0, 0.0f));
+            const float tf = min_(min_(x1, y1), min_(z1, sink.prune_bound()));
             const bool hit = tn <= tf;
-            if (hit && info >= 0) {
-                if (leaf2 >= 0) break;       // a third leaf: it is met again (and counted) next time round
-                if (leaf >= 0) leaf2 = info; else leaf = info;
-                node = skip;
-            } else {
-                node = hit ? (info == -1 ? node + 1 : -info - 2) : skip;   // inner node: first child, given or next
-            }
-            ++visited;
-            bc.nodes++;
+            const bool take = hit && info >= 0;          // a leaf the ray may touch
+            const bool third = take && leaf2 >= 0;
+            const int32_t next = (hit && info < 0) ? -2 - info : skip;   // inner node: its first child
+            leaf2 = (take && leaf >= 0 && !third) ? info : leaf2;
+            leaf = (take && leaf < 0) ? info : leaf;
+            node = third ? node : next;
+            visited += third ? 0 : 1;
+            open = !third;
         }
+        bc.nodes += (uint32_t)(visited - visited0);
         PROF(kProfWalk);
         if (leaf >= 0) {
             const int first = leaf >> 4, cnt0 = leaf & 15;
             const int first2 = leaf2 >= 0 ? leaf2 >> 4 : 0, cnt = cnt0 + (leaf2 >= 0 ? leaf2 & 15 : 0);
             bc.tris += (uint32_t)cnt;
             for (int k = 0; k < cnt; ++k) {
+                PROF_LANES(kProfLeafIters, (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))); PROF_LANES(kProfLeafLanes, true);
                 const TriRow cur = load_tri_row_lane(rows, k < cnt0 ? first + k : first2 + (k - cnt0));
                 float sure_thi;
                 const float tl = tri_tlo<true>(cur, r, &sure_thi);

@@ -433,6 +433,7 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
         }
         if (__ballot(have_job) == 0) break;
         PROF(kProfHandout);
+        PROF_LANES(kProfLanesJob, have_job);
 
         // Statistics: every lane counts its own closest-hit queries and environment lookups (one add
         // each, where the code runs anyway; summed over the wave at the end of the kernel); the two
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
                 const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio);
                 const RayResidue rr = path_residue(S, A.ray_res, p);
                 PROF(kProfRaySetup);
+                PROF_LANES(kProfLanesStart, !walking);
                 if (!walking) {
                     walking = true;
                     walk_node = -1;
@@ -466,16 +468,18 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
 #else
                 // (path mode: every lane holds a path that went deep or grazed something - longer slices, fewer trips)
                 const int walk_slice = (!LEAN && JOB(path_mode)) ? 4 * kWalkSlice : kWalkSlice;
-                constexpr int more_below = 16, more_times = 1;
+                constexpr int more_below = 32, more_times = 2;
 #endif
                 if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
                 // When only a few lanes are through, closing their queries now would run ~1,000
-                // instructions for them alone: the wave walks one more slice first.  (Measured at
-                // 1.18 M triangles: thresholds 8 / 16 / 24 -> 5.05 / 5.10 / 5.06 against 4.86 G rays/s
-                // without; repeating the extra slice two to four times: 4.97 ... 4.81.)
+                // instructions for them alone: the wave walks another slice first, up to twice, while fewer than half
+                // its lanes are through.  (Measured at 1.18 M triangles, kernel time for 32 samples per pixel: no
+                // extra slice 50.7 ms; one while fewer than 16 lanes are through 49.0; than 32: 48.5; two while fewer
+                // than 32: 47.4; than 48: 50.0; walking until every lane is through: 80.8.)
                 for (int k = 0; k < more_times && __builtin_popcountll(__ballot(walk_node < 0)) < more_below; ++k) {
                     if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
                 }
+                PROF_LANES(kProfLanesEnd, walk_node < 0);
                 if (walk_node < 0) {
                     walking = false;
                     BvhCounters second_pass = bc; second_pass.nodes = 0; second_pass.tris = 0;

@@ -97,9 +97,9 @@ struct MatRow {      // 8 dwords per object
     float r, g, b, emission, smoothness, transmittance, ior, r0;  // r0 = ((1-ior)/(1+ior))^2
 };
 
-struct BvhNode {     // mirrors rt_bvh_node
-    float lo[3]; int32_t skip;
-    float hi[3]; int32_t tri_begin_count;
+struct BvhNode {     // rt_bvh_node as the device holds it, per octant copy: `lo` = the planes rays of that octant enter
+    float lo[3]; int32_t skip;             // through, `hi` = the planes they leave through (swapped per axis where the
+    float hi[3]; int32_t tri_begin_count;  // octant's direction is negative); inner nodes: -(first child + 2), never -1
 };
 
 // Scene data only the rare double-precision code, the depth-of-field camera and the ray-generation

@@ -8,6 +8,7 @@ import helpers as h
 from raytracing_amd.backend.lib import HipBackend
 NAMES = ["handout", "begin", "ray_setup", "spheres", "big_spheres", "quad_rows", "slab_rows", "tri_rows", "judge", "settle",
          "record", "sky", "draws", "bounce", "accum", "stats", "walk", "leaves"]
+COUNTS = ["trips", "lanes_with_job", "lanes_starting", "lanes_ending", "walk_iters", "walk_lanes", "leaf_iters", "leaf_lanes"]
 name = sys.argv[1] if len(sys.argv) > 1 else "room"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 be = HipBackend(0)
@@ -25,11 +26,18 @@ be.render(W, H, 0, 4, 8, 1); be.synchronize()
 be.reset_stats()
 be.render(W, H, 0, spp, 8, 1); be.synchronize()
 st = be.stats()
-out = (C.c_uint64 * 18)()
+out = (C.c_uint64 * 26)()
 be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
-be.lib.rt_debug_section_cycles(be.handle, out, 18)
+be.lib.rt_debug_section_cycles(be.handle, out, 26)
+counts = list(out)[18:]; out = list(out)[:18]
 tot = sum(out)
 iters = st["rays"] / 64.0
 print(f"{name} {spp} spp: kernel {st['kernel_ms']:.2f} ms, rays {st['rays']}, wave-iterations {iters:.3e}, cycles/iteration (wave view) {tot / iters:.0f}")
 for n, v in zip(NAMES, out):
     print(f"  {n:12s} {100.0 * v / tot:6.2f} %   {v / iters:8.1f} cycles / iteration")
+trips = max(counts[0], 1)
+print(f"  trips of the render loop {counts[0]} ({st['rays'] / 64.0 / trips:.3f} of 64 rays closed per trip); lanes per trip: with a job {counts[1] / trips:.1f}, "
+      f"starting a query {counts[2] / trips:.1f}, closing one {counts[3] / trips:.1f}   (hierarchy scenes; all kernels of the call)")
+if counts[4]:
+    print(f"  box loop: {counts[4] / trips:.2f} passes per trip, {counts[5] / counts[4]:.1f} lanes in a pass; triangle loop: {counts[6] / trips:.2f} passes per trip, "
+          f"{counts[7] / max(counts[6], 1):.1f} lanes in a pass")
