@@ -710,8 +710,8 @@ RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
 // beyond the sink's bound.
 typedef const f4 __attribute__((address_space(3))) *lds_f4_ptr;
 #ifndef RT_WALK_FLAT
-#define RT_WALK_FLAT 1   // 1: one load through a generic pointer (LDS or memory) per node; 0: a branch with a load on either
-                         // side; 2: memory only.  Measured at 1.18 M triangles, 32 samples per pixel: 46.5 / 48.3 / 46.7 ms
+#define RT_WALK_FLAT 1   // 1: one load through a generic pointer (LDS or memory) per node; 2: memory only (measured equal:
+                         // 44.3 against 44.5 ms at 1.18 M triangles, 32 samples per pixel; a branch with a load on either side: +1.6 ms)
 #endif
 
 // Per-query walk context: test counters, and where the top levels of the hierarchy sit in LDS (if the
@@ -747,35 +747,32 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
     const TriRow *rows = S.leaf_rows;
     if (S.n_bvh_nodes <= 0) node = -1;
     int visited = 0;
-    // Each trip of the outer loop is a sub-slice: every lane walks boxes until it has found two leaves
-    // (after the first it goes on - the leaf waits), stands before a third, or has used the sub-slice
-    // up; then all lanes that hold leaves test their triangles TOGETHER.  Testing a leaf the moment a
-    // lane finds it would run the triangle code for that one lane while the others wait ("while-while"
-    // loops still did that three or four times per slice).
-    // Measured at 1.18 M triangles, G rays/s: one pending leaf, sub-slices of 2 / 4 / 8 boxes:
-    // 4.58 / 4.84 / 4.72; two pending leaves, sub-slices of 4 / 6 / 8: 5.32 / 5.37 / 5.43; three: 5.60 against 5.55.
+    // Each trip of the outer loop is a sub-slice: every lane walks boxes until it holds three leaves
+    // (after the first it goes on - the leaves wait) or has used the sub-slice up; then all lanes that
+    // hold leaves test their triangles TOGETHER.  Testing a leaf the moment a lane finds it would run
+    // the triangle code for that one lane while the others wait ("while-while" loops still did that
+    // three or four times per slice).
+    // Measured at 1.18 M triangles, G rays/s, with the loop body as nested ifs: one pending leaf, sub-slices
+    // of 2 / 4 / 8 boxes: 4.58 / 4.84 / 4.72; two pending leaves (stopping before a third), sub-slices of
+    // 4 / 6 / 8: 5.32 / 5.37 / 5.43.  With the branch-free body, kernel time for 32 samples per pixel: two
+    // pending leaves, stopping before a third 46.2 ms; stopping once two are held 48.6; three held 44.3.
     constexpr int kSubSlice = 8;
     while (visited < budget && node >= 0) {
         const int stop = visited + kSubSlice < budget ? visited + kSubSlice : budget;
         const int visited0 = visited;
-        int32_t leaf = -1, leaf2 = -1;
-        bool open = true;   // false: the lane stands before a third leaf (met again, and counted, next time round)
+        int32_t leaf = -1, leaf2 = -1, leaf3 = -1;
         // The body is written without branches (selects only): as nested ifs it compiled to some forty
-        // scalar mask and branch instructions per box, more than the box test itself.
-        while (open && node >= 0 && visited < stop) {
+        // scalar mask and branch instructions per box, more than the box test itself.  Leaves are held
+        // newest first.
+        while (node >= 0 && visited < stop && leaf3 < 0) {
             PROF_LANES(kProfWalkIters, (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))); PROF_LANES(kProfWalkLanes, true);
 #if RT_WALK_FLAT == 2
             const f4 *q = nodes + 2 * (size_t)node;
-            const f4 a = q[0], b = q[1];
-#elif RT_WALK_FLAT
+#else
             // top levels from LDS, the rest from memory, through ONE load: the pointer says which
             const f4 *q = node < bc.n_top ? (const f4 *)(top + 2 * node) : nodes + 2 * (size_t)node;
-            const f4 a = q[0], b = q[1];
-#else
-            f4 a, b;
-            if (node < bc.n_top) { a = top[2 * node]; b = top[2 * node + 1]; }                // top levels: LDS
-            else { a = nodes[2 * (size_t)node]; b = nodes[2 * (size_t)node + 1]; }
 #endif
+            const f4 a = q[0], b = q[1];
             const int32_t skip = (int32_t)f2u(a.w), info = (int32_t)f2u(b.w);
             const float x0 = fma_(a.x, ix, knx), y0 = fma_(a.y, iy, kny), z0 = fma_(a.z, iz, knz);
             const float x1 = fma_(b.x, ix, kfx), y1 = fma_(b.y, iy, kfy), z1 = fma_(b.z, iz, kfz);
@@ -783,23 +780,28 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
             const float tf = min_(min_(x1, y1), min_(z1, sink.prune_bound()));
             const bool hit = tn <= tf;
             const bool take = hit && info >= 0;          // a leaf the ray may touch
-            const bool third = take && leaf2 >= 0;
-            const int32_t next = (hit && info < 0) ? -2 - info : skip;   // inner node: its first child
-            leaf2 = (take && leaf >= 0 && !third) ? info : leaf2;
-            leaf = (take && leaf < 0) ? info : leaf;
-            node = third ? node : next;
-            visited += third ? 0 : 1;
-            open = !third;
+            leaf3 = take ? leaf2 : leaf3;
+            leaf2 = take ? leaf : leaf2;
+            leaf = take ? info : leaf;
+            node = (hit && info < 0) ? -2 - info : skip;   // inner node: its first child
+            ++visited;
         }
         bc.nodes += (uint32_t)(visited - visited0);
         PROF(kProfWalk);
         if (leaf >= 0) {
-            const int first = leaf >> 4, cnt0 = leaf & 15;
-            const int first2 = leaf2 >= 0 ? leaf2 >> 4 : 0, cnt = cnt0 + (leaf2 >= 0 ? leaf2 & 15 : 0);
+            // oldest first: candidates then reach the sink in the order the walk meets them, wherever its slices end
+            // (among candidates with equal lower bounds - 0 for everything that starts behind the origin - the sink
+            // keeps the first, so how a query gets settled, though not its result, depends on that order)
+            const int32_t la = leaf3 >= 0 ? leaf3 : (leaf2 >= 0 ? leaf2 : leaf);
+            const int32_t lb = leaf3 >= 0 ? leaf2 : (leaf2 >= 0 ? leaf : -1);
+            const int32_t lc = leaf3 >= 0 ? leaf : -1;
+            const int first = la >> 4, cnt0 = la & 15;
+            const int first2 = lb >= 0 ? lb >> 4 : 0, cnt1 = cnt0 + (lb >= 0 ? lb & 15 : 0);
+            const int first3 = lc >= 0 ? lc >> 4 : 0, cnt = cnt1 + (lc >= 0 ? lc & 15 : 0);
             bc.tris += (uint32_t)cnt;
             for (int k = 0; k < cnt; ++k) {
                 PROF_LANES(kProfLeafIters, (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))); PROF_LANES(kProfLeafLanes, true);
-                const TriRow cur = load_tri_row_lane(rows, k < cnt0 ? first + k : first2 + (k - cnt0));
+                const TriRow cur = load_tri_row_lane(rows, k < cnt0 ? first + k : (k < cnt1 ? first2 + (k - cnt0) : first3 + (k - cnt1)));
                 float sure_thi;
                 const float tl = tri_tlo<true>(cur, r, &sure_thi);
                 sink.certain_hit(sure_thi);
