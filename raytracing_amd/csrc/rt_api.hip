@@ -212,8 +212,8 @@ int rt_create(int device_id, rt_ctx **out) {
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount;
     if (hipSetDevice(device_id) != hipSuccess || c->job_counter.ensure(256) != hipSuccess ||
-        c->stats.ensure(sizeof(unsigned long long) * (kStatCount + kProfCount)) != hipSuccess ||
-        hipMemset(c->stats.p, 0, sizeof(unsigned long long) * (kStatCount + kProfCount)) != hipSuccess) {
+        c->stats.ensure(sizeof(unsigned long long) * (kStatCount + 2 * kProfCount)) != hipSuccess ||
+        hipMemset(c->stats.p, 0, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount)) != hipSuccess) {
         delete c;
         return fail(nullptr, RT_ERR_HIP, "device %d: initial allocation failed", device_id);
     }
@@ -1228,6 +1228,9 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
         // the paths set aside: the full kernel's job loop over the records, one path each
         RenderArgs Q = A;
         Q.path_mode = 1; Q.job_list_count = A.aside_count; Q.job_counter = A.job_counter + 4;
+#ifdef RT_SECTION_TIMERS
+        Q.prof = A.prof + kProfCount;   // (a bank of its own for the path-list launch)
+#endif
         hipLaunchKernelGGL((k_render<TRI, SPH, false, false>), dim3(std::min(blocks, (unsigned)c->n_cu * 4)), dim3(256), 0, stream, S, Q);
         // the jobs given up: the same job loop over the list (nearly always an empty one)
         RenderArgs R = A;
@@ -1355,9 +1358,9 @@ int rt_debug_section_cycles(rt_ctx *c, unsigned long long *out, int n) {
     if (!c || !out) return RT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
-    unsigned long long v[kProfCount];
+    unsigned long long v[2 * kProfCount];
     HIP_TRY(c, hipMemcpy(v, c->stats.as<unsigned long long>() + kStatCount, sizeof v, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n && i < kProfCount; ++i) out[i] = v[i];
+    for (int i = 0; i < n && i < 2 * kProfCount; ++i) out[i] = v[i];
     return RT_OK;
 }
 #endif
@@ -1367,7 +1370,7 @@ int rt_reset_stats(rt_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     drain_events(c);
-    HIP_TRY(c, hipMemset(c->stats.p, 0, sizeof(unsigned long long) * (kStatCount + kProfCount)));
+    HIP_TRY(c, hipMemset(c->stats.p, 0, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount)));
     { std::lock_guard<std::mutex> g(c->mu); c->kernel_ms = 0; c->launches = 0; c->paths_launched = 0; c->kernel_ms_min = c->kernel_ms_max = 0; c->launches_timed = 0; }
     return RT_OK;
 }

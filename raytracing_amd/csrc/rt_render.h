@@ -379,6 +379,11 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
         {
             const int n_idle = __builtin_popcountll(idle);
             if (n_idle < (TRI == kTriBrute ? 4 : 2) && n_idle != 64) idle = 0;
+            // Path mode: a wave takes 64 records and sees them through TOGETHER before it takes more.  Every record
+            // begins with the query that needs the double-precision code - thousands of instructions, worth running
+            // once for 64 lanes, not once per refilled lane (measured: 2,200 instructions per path at 7 active lanes
+            // with lane-by-lane refill).
+            if (!LEAN && JOB(path_mode) && n_idle != 64) idle = 0;
         }
         while (idle != 0 && !(drained && win_next == win_end)) {
             if (win_next == win_end) {
@@ -476,6 +481,14 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
                 // its lanes are through.  (Measured at 1.18 M triangles, kernel time for 32 samples per pixel: no
                 // extra slice 50.7 ms; one while fewer than 16 lanes are through 49.0; than 32: 48.5; two while fewer
                 // than 32: 47.4; than 48: 50.0; walking until every lane is through: 80.8.)
+                if (!LEAN && JOB(path_mode)) {
+                    // (path mode: all lanes close their queries in the same trip, see the hand-out above.  Measured at
+                    // 1.18 M triangles, 780 k paths set aside: 6.4 ms; going on once three lanes in four are through:
+                    // 6.5; slices and lane-by-lane refill as in the lean kernel: 7.4)
+                    while (__ballot(walk_node >= 0) != 0) {
+                        if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
+                    }
+                } else
                 for (int k = 0; k < more_times && __builtin_popcountll(__ballot(walk_node < 0)) < more_below; ++k) {
                     if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
                 }

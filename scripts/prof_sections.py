@@ -26,18 +26,21 @@ be.render(W, H, 0, 4, 8, 1); be.synchronize()
 be.reset_stats()
 be.render(W, H, 0, spp, 8, 1); be.synchronize()
 st = be.stats()
-out = (C.c_uint64 * 26)()
+N = 26
+raw = (C.c_uint64 * (2 * N))()
 be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
-be.lib.rt_debug_section_cycles(be.handle, out, 26)
-counts = list(out)[18:]; out = list(out)[:18]
-tot = sum(out)
+be.lib.rt_debug_section_cycles(be.handle, raw, 2 * N)
 iters = st["rays"] / 64.0
-print(f"{name} {spp} spp: kernel {st['kernel_ms']:.2f} ms, rays {st['rays']}, wave-iterations {iters:.3e}, cycles/iteration (wave view) {tot / iters:.0f}")
-for n, v in zip(NAMES, out):
-    print(f"  {n:12s} {100.0 * v / tot:6.2f} %   {v / iters:8.1f} cycles / iteration")
-trips = max(counts[0], 1)
-print(f"  trips of the render loop {counts[0]} ({st['rays'] / 64.0 / trips:.3f} of 64 rays closed per trip); lanes per trip: with a job {counts[1] / trips:.1f}, "
-      f"starting a query {counts[2] / trips:.1f}, closing one {counts[3] / trips:.1f}   (hierarchy scenes; all kernels of the call)")
-if counts[4]:
-    print(f"  box loop: {counts[4] / trips:.2f} passes per trip, {counts[5] / counts[4]:.1f} lanes in a pass; triangle loop: {counts[6] / trips:.2f} passes per trip, "
-          f"{counts[7] / max(counts[6], 1):.1f} lanes in a pass")
+print(f"{name} {spp} spp: kernel {st['kernel_ms']:.2f} ms, rays {st['rays']}, wave-iterations {iters:.3e}; set aside: {be.render_counters()}")
+for bank, title in ((0, "lean kernel (+ jobs rendered again)"), (1, "full kernel over the paths set aside")):
+    out = list(raw)[bank * N:bank * N + 18]; counts = list(raw)[bank * N + 18:(bank + 1) * N]
+    tot = sum(out)
+    if tot == 0: continue
+    print(f" {title}: cycles/iteration (wave view) {tot / iters:.0f}")
+    for n, v in zip(NAMES, out):
+        print(f"  {n:12s} {100.0 * v / tot:6.2f} %   {v / iters:8.1f} cycles / iteration")
+    trips = max(counts[0], 1)
+    print(f"  trips of the render loop {counts[0]}; lanes per trip: with a job {counts[1] / trips:.1f}, starting a query {counts[2] / trips:.1f}, closing one {counts[3] / trips:.1f} (hierarchy scenes)")
+    if counts[4]:
+        print(f"  box loop: {counts[4] / trips:.2f} passes per trip, {counts[5] / counts[4]:.1f} lanes in a pass; triangle loop: {counts[6] / trips:.2f} passes per trip, "
+              f"{counts[7] / max(counts[6], 1):.1f} lanes in a pass")
