@@ -87,7 +87,7 @@ def roofline_of(st: dict, kernel: str, traffic_file: str | None, mode: str = "de
     out = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / PEAK_FP32_VALU_TFLOPS, "frac_basis": "algorithmic FLOPs (tests executed x per-test constants)",
            "kernel": kernel,
-           "kernel_span": "HIP events around everything one rt_render call launches: the lean kernel named here (97 % of the span), the full "
+           "kernel_span": "HIP events around everything one rt_render call launches: the lean kernel named here (95 % of the span on the room), the full "
                           "kernel over the paths it set aside and over the jobs it gave up, the fold",
            "kernel_ms_per_launch": kernel_s * 1e3, "kernel_ms_min": st["kernel_ms_min"], "kernel_ms_max": st["kernel_ms_max"],
            "flops_per_launch": flops_launch, "rays_per_launch": st["rays"] / launches,
