@@ -412,6 +412,13 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
                     p.tag = rec.tag; p.own_ratio = rec.own_ratio; p.inside = rec.inside != 0u;
                     ar = ag = ab = 0.0;
                     in_path = true; walking = false;
+                    if constexpr (TRI == kTriBvh) {
+                        // the query that was handed back comes with its first pass done (the lean kernel walked it): it is
+                        // closed - judged, settled - in this lane's next trip without another walk
+                        walking = true; walk_node = -1;
+                        first.init(S);
+                        first.lo0 = u2f(rec.pad[0]); first.lo1 = u2f(rec.pad[1]); first.id0 = (int32_t)rec.pad[2];
+                    }
                     have_job = !JOB(dirty)[rec.slot];   // (its job was given up later on: the job list covers it)
                 } else {
                 if (JOB(job_list) != nullptr) job = JOB(job_list)[job];
@@ -561,6 +568,7 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
                             rec.ox = p.ox; rec.oy = p.oy; rec.oz = p.oz; rec.dx = p.dx; rec.dy = p.dy; rec.dz = p.dz;
                             rec.tr = p.tr; rec.tg = p.tg; rec.tb = p.tb; rec.origin = p.origin; rec.tag = p.tag;
                             rec.own_ratio = p.own_ratio; rec.inside = p.inside ? 1u : 0u; rec.pad[0] = rec.pad[1] = rec.pad[2] = 0u;
+                            if constexpr (TRI == kTriBvh) { rec.pad[0] = f2u(first.lo0); rec.pad[1] = f2u(first.lo1); rec.pad[2] = (uint32_t)first.id0; }
                             JOB(aside)[idx] = rec;
                             JOB(head)[slot] = (int32_t)idx;
                             job_last_rec = (int32_t)idx;

@@ -195,7 +195,8 @@ struct AsideRec {
     uint32_t tag;             // TriAux::tag of that primitive
     float own_ratio;          // Hit::own_ratio of the hit the ray leaves from
     uint32_t inside;          // Ray.inside
-    uint32_t pad[3];
+    uint32_t pad[3];          // hierarchy scenes: the first pass's result for that query (PairBest::lo0, lo1, id0 as bits),
+                              // so the full kernel judges and settles it without walking it again
 };
 static_assert(sizeof(AsideRec) == 96, "AsideRec: six 16-byte loads");
 
