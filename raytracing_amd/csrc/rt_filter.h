@@ -730,12 +730,27 @@ RT_DEV BvhCounters bvh_counters() { BvhCounters b; b.nodes = 0; b.tris = 0; b.to
 // slowest ray of the wave (one that grazes a dense mesh visits ten times the average) is through.
 template <class Sink>
 RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, int &node, int budget) {
-    const float ix = rcp_(r.dx), iy = rcp_(r.dy), iz = rcp_(r.dz);
     const float pad = 10.0f * kU * (r.o2 + S.scene_radius);
     // the threading for this ray's octant: children nearer along the ray come first, and every node of
     // that copy holds the planes the ray ENTERS through in its first half, the planes it leaves through
     // in its second - no min / max per axis
-    const bool bx = r.dx < 0.0f, by = r.dy < 0.0f, bz = r.dz < 0.0f;
+    const bool bx = r.dx < 0.0f, by = r.dy < 0.0f, bz = r.dz < 0.0f;   // (-0.0 counts as "not negative")
+    float ix = rcp_(r.dx), iy = rcp_(r.dy), iz = rcp_(r.dz);
+    // Only the second pass ever walks a ray with a zero direction component (ray_route keeps such rays away from
+    // the first pass).  There the reciprocals are capped at 1e18 and take their sign from the octant: a zero
+    // component then gives a slab value of +-(distance to the plane) x 1e18 - far beyond every other axis' values,
+    // with the sign that says on which side of the plane the origin lies - where an infinite reciprocal gives
+    // NaN ("unconstrained") for half the planes and such a ray would visit every box along its other two
+    // axes (measured: 35 such rays per 32 samples per pixel added 2.5 ms to the path launch at 1.18 M
+    // triangles); and -0.0, whose reciprocal is -inf, goes with the plane order of the octant it is filed under
+    // (taken as it is, such a ray entered every box at +inf and missed the whole mesh).  The error bound above
+    // holds for any finite reciprocal - every term scales with it - so a box the ray touches is never dropped.
+    if (Sink::kPerTriangle) {
+        const float cap = 1e18f;
+        ix = bx ? -min_(abs_(ix), cap) : min_(abs_(ix), cap);
+        iy = by ? -min_(abs_(iy), cap) : min_(abs_(iy), cap);
+        iz = bz ? -min_(abs_(iz), cap) : min_(abs_(iz), cap);
+    }
     const int oct = (bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0);
     // entry = plane * (1 / d) + k, one multiply-add per plane; the widening sits in k: the entry value is
     // computed from an origin moved forward along the axis by `pad`, the exit value from one moved back

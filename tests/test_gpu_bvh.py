@@ -97,6 +97,34 @@ def test_axis_parallel_and_far_rays_through_hierarchy(backend):
     _check_hits(backend.intersect(o, d), h.oracle_intersect(sc, o, d))
 
 
+def test_zero_direction_components_through_hierarchy(backend):
+    """Rays with one or two direction components exactly zero, in every sign combination, from origins inside
+    and outside the mesh's box and from origins whose coordinates EQUAL a vertex coordinate (the ray then runs
+    in a box plane of some node: 0 x inf in the walk's slab test).  The walk may only ever visit too many
+    boxes, never too few: hits equal the oracle's (which gates on upstream's 1e10 pseudo-inverse, mesh.py:70-74)."""
+    base = h.packed_scene("room_horse")
+    sc = base.with_subdivided_mesh(base.n_meshes - 1, 2)
+    backend.set_scene(sc)
+    rng = np.random.default_rng(77)
+    n = 6000
+    verts = np.asarray(sc.tri_verts, np.float64).reshape(-1, 3)
+    mesh_verts = verts[3 * 22:]                                   # the subdivided horse (the room's 22 triangles come first)
+    o = (rng.uniform(-1, 1, (n, 3)) * 1.2)
+    pick = mesh_verts[rng.integers(0, len(mesh_verts), n)]
+    on_plane = rng.random((n, 3)) < 0.35                          # some coordinates taken from a mesh vertex
+    o = np.where(on_plane, pick, o).astype(np.float32).astype(np.float64)
+    d = rng.normal(size=(n, 3))
+    zero = rng.random((n, 3)) < 0.5
+    zero[zero.all(axis=1), 0] = False                             # at least one component stays
+    d[zero] = 0.0
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32).astype(np.float64)
+    neg_zero = rng.random((n, 3)) < 0.5                           # -0.0 as well as +0.0
+    d = np.where((d == 0.0) & neg_zero, -0.0, d)
+    assert (d == 0.0).any(axis=1).mean() > 0.7
+    _check_hits(backend.intersect(o, d), h.oracle_intersect(sc, o, d))
+
+
 @pytest.mark.parametrize("levels,n_path,n_rand", [(2, 10004, 20000), (4, 6000, 6000), (6, 1500, 1000)])
 def test_subdivided_mesh_against_oracle(backend, levels, n_path, n_rand):
     """4.6 k, 74 k and 1.18 M triangles (the largest is BASELINE config 4's mesh size): the library
