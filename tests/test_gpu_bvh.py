@@ -121,7 +121,11 @@ def test_zero_direction_components_through_hierarchy(backend):
     d = d.astype(np.float32).astype(np.float64)
     neg_zero = rng.random((n, 3)) < 0.5                           # -0.0 as well as +0.0
     d = np.where((d == 0.0) & neg_zero, -0.0, d)
-    assert (d == 0.0).any(axis=1).mean() > 0.7
+    # and components that are tiny instead of zero, down to float32 denormals, either sign
+    tiny = (d == 0.0) & (rng.random((n, 3)) < 0.3)
+    mag = (10.0 ** -rng.integers(10, 45, (n, 3)).astype(np.float64)).astype(np.float32).astype(np.float64)
+    d = np.where(tiny, np.where(neg_zero, -mag, mag), d)
+    assert (d == 0.0).any(axis=1).mean() > 0.5 and ((d != 0.0) & (np.abs(d) < 1e-9)).any(axis=1).mean() > 0.2
     _check_hits(backend.intersect(o, d), h.oracle_intersect(sc, o, d))
 
 
