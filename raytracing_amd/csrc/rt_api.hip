@@ -1171,7 +1171,7 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     A.ray_dir = c->ray_dir.as<float>(); A.ray_res = c->ray_res.as<float>();
     A.max_bounces = p->max_bounces; A.seed_lo = (uint32_t)p->seed; A.seed_hi = (uint32_t)(p->seed >> 32);
     A.total_jobs = (uint32_t)total_jobs;
-    A.div_rect_px = make_fast_div((uint32_t)rect_px); A.div_rect_h = make_fast_div((uint32_t)A.rect_h); A.job_counter = c->job_counter.as<uint32_t>(); A.accum = accum;
+    A.div_chunks = make_fast_div((uint32_t)n_chunks); A.div_rect_h = make_fast_div((uint32_t)A.rect_h); A.job_counter = c->job_counter.as<uint32_t>(); A.accum = accum;
     A.stats = c->stats.as<unsigned long long>();
 #if defined(RT_SECTION_TIMERS) || defined(RT_ASIDE_REASONS)
     A.prof = A.stats + kStatCount;

@@ -209,10 +209,10 @@ struct RenderArgs {
     int32_t max_bounces;
     uint32_t seed_lo, seed_hi;
     uint32_t total_jobs;
-    FastDiv div_rect_px, div_rect_h;   // job -> (chunk, pixel in rectangle) -> (x, y)
+    FastDiv div_chunks, div_rect_h;    // job -> (pixel in rectangle, chunk) -> (x, y): jobs are numbered pixel by pixel
     uint32_t *job_counter;    // device word, zero at launch
     float *accum;             // (W,H,3) running sum
-    double *partial;          // [n_chunks][rect_w*rect_h][3]: every job's sum over its samples
+    double *partial;          // [rect_w*rect_h][n_chunks][3]: every job's sum over its samples
     // paths set aside by the lean kernel, and jobs it gave up (no room left in the list): see k_render
     AsideRec *aside; uint32_t *aside_count; uint32_t aside_cap;
     uint32_t *dirty_list, *dirty_count; uint8_t *dirty;   // [total_jobs] job ids, their number, one byte per job
