@@ -1157,6 +1157,8 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     // Job granularity: enough (pixel, chunk) jobs that every resident lane runs many of them, so the
     // end-of-launch tail (lanes waiting for the last jobs) stays a few percent of the launch.
     const long long lanes = (long long)c->n_cu * 2048;
+    // (measured with jobs numbered pixel by pixel, factors 24 / 48 / 96 / 192: room 45.96 / 45.61 / 46.86 / 48.46 ms per
+    // 256 spp, 1.18 M triangles 41.25 / 40.72 / 40.99 / 42.22 ms per 32 spp)
     long long want_chunks = (48 * lanes + rect_px - 1) / rect_px;
     int n_chunks = (int)std::min<long long>(std::max<long long>(want_chunks, 1), p->sample_count);
     int chunk_samples = (p->sample_count + n_chunks - 1) / n_chunks;
