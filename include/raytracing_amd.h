@@ -311,8 +311,10 @@ int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t see
 int rt_debug_scene_layout(rt_ctx *ctx, int32_t *out, int32_t n_out, float *box_slack);
 
 /* What the last rt_render call set aside (no upstream counterpart; tests and tuning; synchronises):
- * out4[0] jobs handed out, [1] paths the lean kernel set aside for the full code, [2] jobs it gave
- * up (no room left in the list), [3] jobs handed out again. */
+ * out4[0] the job hand-out counter, [1] paths the lean kernel set aside for the full code, [2] jobs it gave
+ * up (no room left in the list), [3] the hand-out counter of the launch that renders those jobs again.  [0] and [3]
+ * are the counters' final values: every wave overshoots by the window it asked for last, so [3] is non-zero even
+ * when no job was given up. */
 int rt_debug_render_counters(rt_ctx *ctx, uint32_t *out4);
 
 /* Parity / diagnostic hook: traces n_paths whole paths, one device thread each, with the same

@@ -273,7 +273,8 @@ class HipBackend:
         return out
 
     def render_counters(self) -> dict:
-        """What the last ``render`` call set aside (tests and tuning; synchronises)."""
+        """What the last ``render`` call set aside (tests and tuning; synchronises).  ``jobs`` and
+        ``jobs_rendered_again`` are hand-out counters: each wave overshoots them by its last window."""
         out = (C.c_uint32 * 4)()
         self._check(self.lib.rt_debug_render_counters(self.handle, out))
         return dict(jobs=out[0], paths_set_aside=out[1], jobs_given_up=out[2], jobs_rendered_again=out[3])
