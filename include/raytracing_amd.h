@@ -156,10 +156,12 @@ typedef struct rt_stats {
     uint64_t paths;                /* top-level raytrace calls (renderer.py:105) */
     uint64_t sphere_tests, tri_tests, aabb_tests, bvh_node_tests; /* float32 filter tests executed */
     uint64_t exact_rays;           /* rays whose contenders were settled in double precision (second pass or whole-scene scan) */
-    uint64_t refined_hits;         /* hits whose winning primitive was re-evaluated in double precision */
+    uint64_t refined_hits;         /* hits whose winning primitive was re-evaluated in double precision.  (These two are
+                                      diagnostics: when rt_render gives a job up and renders it again - its list of set-aside
+                                      paths was full - what the job had counted here before is counted twice.) */
     uint64_t sky_lookups, shaded_hits;
-    double kernel_ms;              /* device time of the dominant kernel (rt_render: the render kernel alone, without the
-                                      short fold of the per-job slots that follows it), summed over launches */
+    double kernel_ms;              /* device time of the call's kernels (rt_render: everything the call launches - the render
+                                      kernel, the launches over set-aside paths and given-up jobs, the fold), summed over launches */
     uint64_t launches;
     double kernel_ms_min, kernel_ms_max;   /* shortest and longest single launch (0 without launches): shows an outlier a mean hides */
 } rt_stats;

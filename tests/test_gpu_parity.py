@@ -1221,6 +1221,7 @@ def test_lean_kernel_with_set_aside_paths_equals_full_kernel(backend, scene, W, 
     whole-image calls and in tiles, and the statistics must agree (strict depth: both flags take the full kernel)."""
     _set(backend, scene)
     out = {}
+    given_up = 0
     for no_defer in (True, False):
         backend.resize(W, H)
         backend.reset_stats()
@@ -1232,6 +1233,7 @@ def test_lean_kernel_with_set_aside_paths_equals_full_kernel(backend, scene, W, 
             # the roads the docstring names were really taken: paths set aside, and at 48x27 jobs given up for want of room
             cnt = backend.render_counters()
             assert cnt["paths_set_aside"] > 0 and (cnt["jobs_given_up"] > 0) == (W == 48), cnt
+            given_up = cnt["jobs_given_up"]
         backend.resize(W, H)
         for rect in ((0, W // 2, 0, H), (W // 2, W, 0, H // 3), (W // 2, W, H // 3, H)):
             backend.render(W, H, 0, spp, 8, h.SEED_RENDER, rect=rect, no_defer=no_defer, strict_depth=strict)
@@ -1241,8 +1243,16 @@ def test_lean_kernel_with_set_aside_paths_equals_full_kernel(backend, scene, W, 
     assert np.isfinite(lean[0]).all() and lean[0].sum() > 0
     assert np.array_equal(lean[0], full[0]), f"{int((lean[0] != full[0]).any(axis=2).sum())} pixels differ"
     assert np.array_equal(lean[2], full[2]) and np.array_equal(lean[2], lean[0])
-    for k in ("rays", "paths", "sky_lookups", "shaded_hits", "exact_rays", "refined_hits", "sphere_tests"):
+    for k in ("rays", "paths", "sky_lookups", "shaded_hits", "sphere_tests"):
         assert lean[1][k] == full[1][k], (k, lean[1][k], full[1][k])
+    # the two diagnostic counters of double-precision work are kept per wave and not taken back when a job is given up:
+    # the samples such a job had traced before are then counted twice (once by the lean kernel, once when the job is
+    # rendered again)
+    for k in ("exact_rays", "refined_hits"):
+        if strict or not given_up:
+            assert lean[1][k] == full[1][k], (k, lean[1][k], full[1][k])
+        else:
+            assert full[1][k] <= lean[1][k] <= 1.05 * full[1][k] + 16, (k, lean[1][k], full[1][k])
     # (with a hierarchy the leaf tests of a set-aside path's first segments are counted twice: by the lean kernel and by the full one)
     assert abs(lean[1]["tri_tests"] - full[1]["tri_tests"]) <= (2e-2 * full[1]["tri_tests"] if scene == "room_horse" else 0)
     assert full[1]["exact_rays"] + full[1]["refined_hits"] > 0          # some paths did go aside
