@@ -1244,7 +1244,12 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
         hipLaunchKernelGGL((k_render<TRI, SPH, false, false>), dim3(std::min(blocks, (unsigned)c->n_cu * 4)), dim3(256), 0, stream, S, R);
     });
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((rect_px + 255) / 256)), dim3(256), 0, stream, A);
+    if (n_chunks <= 256) {
+        const int px_per_block = 256 / n_chunks;
+        hipLaunchKernelGGL(k_reduce_jobs, dim3((unsigned)((rect_px + px_per_block - 1) / px_per_block)), dim3(256), 0, stream, A, px_per_block);
+    } else {
+        hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((rect_px + 255) / 256)), dim3(256), 0, stream, A);
+    }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(ev.b, stream));   // (the timed span is everything the call launched: render, set-aside paths, jobs again, fold)
     { std::lock_guard<std::mutex> g(c->mu); c->timed.push_back(ev); c->launches++; c->paths_launched += (uint64_t)rect_px * (uint64_t)p->sample_count; }

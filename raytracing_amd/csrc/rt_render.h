@@ -640,6 +640,39 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const RenderArgs A) {
     dst[0] += (float)r; dst[1] += (float)g; dst[2] += (float)b;
 }
 
+// The same fold with one thread per JOB: consecutive threads read consecutive slots, and the chains of set-aside
+// records - up to a few hundred dependent loads on a pixel whose every path was set aside - are walked per job, a
+// block's worth side by side, not one after the other by the pixel's one thread.  A block takes as many whole pixels
+// as fit 256 threads; the pixel's first thread then adds the jobs' sums up in chunk order.  (For n_chunks <= 256.)
+__global__ __launch_bounds__(256) void k_reduce_jobs(const RenderArgs A, const int px_per_block) {
+    __shared__ double sums[256][6];
+    const uint32_t rect_px = (uint32_t)(A.rect_w * A.rect_h), n = (uint32_t)A.n_chunks;
+    const uint32_t q = threadIdx.x / n, c = threadIdx.x - q * n;           // pixel of the block, chunk
+    const uint32_t pl = blockIdx.x * (uint32_t)px_per_block + q;
+    const bool live = q < (uint32_t)px_per_block && pl < rect_px;
+    double r = 0, g = 0, b = 0, rr = 0, rg = 0, rb = 0;
+    if (live) {
+        const size_t slot = (size_t)pl * n + c;
+        const double *src = A.partial + 3 * slot;
+        r = src[0]; g = src[1]; b = src[2];
+        if (A.head != nullptr) {
+            const int first = A.dirty[slot] ? -1 : A.head[slot];
+            for (int i = first; i >= 0; i = A.aside[i].next) { rr += (double)A.aside[i].r; rg += (double)A.aside[i].g; rb += (double)A.aside[i].b; }
+        }
+    }
+    double *mine = sums[threadIdx.x];
+    mine[0] = r; mine[1] = g; mine[2] = b; mine[3] = rr; mine[4] = rg; mine[5] = rb;
+    __syncthreads();
+    if (live && c == 0) {
+        double tr = 0, tg = 0, tb = 0;
+        for (uint32_t k = 0; k < n; ++k) { const double *t = sums[threadIdx.x + k]; tr += t[0]; tg += t[1]; tb += t[2]; }
+        for (uint32_t k = 0; k < n; ++k) { const double *t = sums[threadIdx.x + k]; tr += t[3]; tg += t[4]; tb += t[5]; }
+        const int px = A.x0 + (int)(pl / (uint32_t)A.rect_h), py = A.y0 + (int)(pl % (uint32_t)A.rect_h);
+        float *dst = A.accum + 3 * ((size_t)px * A.height + py);
+        dst[0] += (float)tr; dst[1] += (float)tg; dst[2] += (float)tb;
+    }
+}
+
 // Diagnostic / parity kernel: one thread traces one whole path and records every segment.
 struct TraceArgs {
     int32_t n_paths, width, height, max_bounces, seg_cap;
