@@ -12,7 +12,7 @@ def counters(name):
     """{counter: value} summed over every k_render dispatch of pass `name` (one rt_render call: the lean kernel,
     the full kernel over the set-aside paths and over the given-up jobs) plus the fold kernel."""
     files = glob.glob(f"{root}/{name}/**/*counter_collection.csv", recursive=True)
-    rows = [r for f in files for r in csv.DictReader(open(f)) if "k_render" in r["Kernel_Name"] or "k_reduce_chunks" in r["Kernel_Name"]]
+    rows = [r for f in files for r in csv.DictReader(open(f)) if "k_render" in r["Kernel_Name"] or "k_reduce_" in r["Kernel_Name"]]
     out = {}
     for r in rows:
         out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
