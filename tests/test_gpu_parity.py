@@ -279,6 +279,25 @@ def test_chunked_and_direct_accumulation_agree(backend):
     assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
 
 
+def test_many_chunks_per_pixel_fold_the_same(backend):
+    """A tiny rectangle with thousands of samples per pixel is cut into more than 256 jobs per pixel, which the
+    fold handles with its one-thread-per-pixel form; the same samples in calls of 240 (30 jobs per pixel, the
+    one-thread-per-job form) must add up to the same image, up to the float32 rounding of each call's sum."""
+    _set(backend, "room")
+    W, H, spp = 16, 9, 2400
+    backend.resize(W, H)
+    backend.render(W, H, 0, spp, 8, 3)
+    backend.synchronize()
+    a = backend.read()
+    backend.clear()
+    for s0 in range(0, spp, 240):
+        backend.render(W, H, s0, 240, 8, 3)
+    backend.synchronize()
+    b = backend.read()
+    assert np.isfinite(a).all() and a.sum() > 0
+    assert np.allclose(a, b, rtol=2e-6, atol=1e-5), np.abs(a - b).max()
+
+
 def test_error_reporting(backend):
     from raytracing_amd.backend.lib import BackendError, HipBackend
 
