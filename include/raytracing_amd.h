@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -136,19 +136,19 @@ enum {
     /* Hierarchy scenes: the wavefront form of the render (generate / extend / shade / resolve kernels
      * over path queues in memory) instead of the single persistent kernel. */
     RT_RENDER_WAVEFRONT = 1,
-    /* Accept a float32 hit depth only when its error BOUND is below 9.5e-6 of the depth, as
-     * rt_intersect_batch does; otherwise redo it in double precision (measured against upstream's
-     * doubles: every depth within 1e-6 relative).  Without the flag the render accepts bounds up to
-     * 2e-4 of the depth, or 1e-5 of the scene size as a distance: hit identity is exact either way;
-     * about 2 in 10,000 depths then differ from upstream's by more than 1e-5 relative (grazing hits
-     * and very short rays), none by more than the bound.  The strict mode costs about 30 % more
-     * render time (a tenth of the rays need the double-precision code). */
+    /* The default since ABI version 3, kept as a name: a float32 hit depth is accepted only when its error
+     * BOUND is below 9.5e-6 of the depth, as rt_intersect_batch does; otherwise it is redone in double
+     * precision (measured against upstream's doubles: every depth within 1e-6 relative).  Hit identity is
+     * exact in every mode. */
     RT_RENDER_STRICT_DEPTH = 2,
-    /* Render with the one kernel that holds all the code.  Without the flag (and without STRICT_DEPTH)
-     * rt_render runs a lean kernel that sets the few paths needing double-precision settling aside,
-     * traces those again with the full code and folds them in: same paths, same image up to the
-     * rounding of a double-precision sum to float32, faster.  For A/B runs and tests. */
-    RT_RENDER_NO_DEFER = 4
+    /* Render with the one kernel that holds all the code.  Without the flag rt_render runs a lean kernel
+     * that sets the few paths needing double-precision settling aside, traces those again with the full
+     * code and folds them in: same paths, same image bit for bit, faster.  For A/B runs and tests. */
+    RT_RENDER_NO_DEFER = 4,
+    /* For A/B runs: the looser depth acceptance of earlier versions - error bounds up to 2e-4 of the depth,
+     * or 1e-5 of the scene size as a distance; about 2 in 10,000 depths then differ from upstream's by more
+     * than 1e-5 relative (grazing hits and very short rays), none by more than the bound. */
+    RT_RENDER_LOOSE_DEPTH = 8
 };
 
 typedef struct rt_stats {
@@ -324,7 +324,7 @@ int rt_debug_render_counters(rt_ctx *ctx, uint32_t *out4);
  * renderer.py:21-79), and records every segment.  xys = [n_paths][3] (x, y, sample index).  Outputs
  * are host arrays; per-segment arrays hold max_bounces + 1 entries per path: hit object / primitive
  * (-1 = miss), which code produced the hit (see rt_intersect_batch), depth, ray origin, direction.
- * render_flags: RT_RENDER_STRICT_DEPTH or 0, as rt_render takes it. */
+ * render_flags: 0 or RT_RENDER_LOOSE_DEPTH, as rt_render takes it. */
 int rt_debug_trace_paths(rt_ctx *ctx, int32_t n_paths, const int32_t *xys, int32_t width, int32_t height,
                          int32_t max_bounces, uint64_t seed, uint32_t render_flags, float *rgb, int32_t *n_seg, int32_t *seg_obj,
                          int32_t *seg_prim, int32_t *seg_how, float *seg_t, float *seg_org, float *seg_dir);

@@ -35,7 +35,7 @@ class RtRenderParams(C.Structure):
                 ("seed", C.c_uint64), ("flags", C.c_uint32), ("wavefront_paths", C.c_int32)]
 
 
-RT_RENDER_WAVEFRONT, RT_RENDER_STRICT_DEPTH, RT_RENDER_NO_DEFER = 1, 2, 4
+RT_RENDER_WAVEFRONT, RT_RENDER_STRICT_DEPTH, RT_RENDER_NO_DEFER, RT_RENDER_LOOSE_DEPTH = 1, 2, 4, 8
 
 
 class RtPostprocessParams(C.Structure):
@@ -197,12 +197,13 @@ class HipBackend:
 
     # -- render ---------------------------------------------------------------------------------
     def render(self, width: int, height: int, sample_begin: int, sample_count: int, max_bounces: int, seed: int,
-               rect=None, accum_ptr: int = 0, stream: int = 0, strict_depth: bool = False, wavefront=None,
+               rect=None, accum_ptr: int = 0, stream: int = 0, strict_depth: bool = True, wavefront=None,
                wavefront_paths: int = 0, no_defer=None) -> None:
         """``wavefront`` None takes the switch from the environment (RAYTRACING_AMD_WAVEFRONT /
         RAYTRACING_AMD_WF_PATHS: A/B runs and tests); the library itself reads no environment variable.
         ``no_defer`` (None: RAYTRACING_AMD_NO_DEFER): the one full kernel instead of the lean kernel
-        plus the set-aside paths (``RT_RENDER_NO_DEFER``)."""
+        plus the set-aside paths (``RT_RENDER_NO_DEFER``).  ``strict_depth=False`` asks for the looser depth
+        acceptance of earlier versions (``RT_RENDER_LOOSE_DEPTH``, A/B runs only)."""
         x0, x1, y0, y1 = rect if rect is not None else (0, width, 0, height)
         if wavefront is None:
             wavefront = bool(os.environ.get("RAYTRACING_AMD_WAVEFRONT"))
@@ -212,7 +213,7 @@ class HipBackend:
                 wavefront_paths = 0
         if no_defer is None:
             no_defer = bool(os.environ.get("RAYTRACING_AMD_NO_DEFER"))
-        flags = (RT_RENDER_WAVEFRONT if wavefront else 0) | (RT_RENDER_STRICT_DEPTH if strict_depth else 0) | (RT_RENDER_NO_DEFER if no_defer else 0)
+        flags = (RT_RENDER_WAVEFRONT if wavefront else 0) | (0 if strict_depth else RT_RENDER_LOOSE_DEPTH) | (RT_RENDER_NO_DEFER if no_defer else 0)
         p = RtRenderParams(C.sizeof(RtRenderParams), width, height, x0, x1, y0, y1, sample_begin, sample_count,
                            max_bounces, seed & 0xFFFFFFFFFFFFFFFF, flags, max(0, int(wavefront_paths)))
         self._check(self.lib.rt_render(self.handle, C.byref(p), C.c_void_p(accum_ptr or None), C.c_void_p(stream or None)))
@@ -308,7 +309,7 @@ class HipBackend:
                                                out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
-    def trace_paths(self, xys, width: int, height: int, max_bounces: int, seed: int, strict_depth: bool = False) -> dict:
+    def trace_paths(self, xys, width: int, height: int, max_bounces: int, seed: int, strict_depth: bool = True) -> dict:
         """Whole paths with per-segment records (diagnostics / parity tests)."""
         xys = np.ascontiguousarray(xys, dtype=np.int32).reshape(-1, 3)
         n, cap = xys.shape[0], max_bounces + 1
@@ -318,7 +319,7 @@ class HipBackend:
         ip, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
         self._check(self.lib.rt_debug_trace_paths(
             self.handle, n, xys.ctypes.data_as(ip), width, height, max_bounces, seed & 0xFFFFFFFFFFFFFFFF,
-            RT_RENDER_STRICT_DEPTH if strict_depth else 0,
+            0 if strict_depth else RT_RENDER_LOOSE_DEPTH,
             out["rgb"].ctypes.data_as(fp), out["n_seg"].ctypes.data_as(ip), out["obj"].ctypes.data_as(ip),
             out["prim"].ctypes.data_as(ip), out["how"].ctypes.data_as(ip), out["t"].ctypes.data_as(fp),
             out["org"].ctypes.data_as(fp), out["dir"].ctypes.data_as(fp)))

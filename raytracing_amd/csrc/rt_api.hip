@@ -97,6 +97,7 @@ struct rt_ctx {
     DevScene S{};
     int tri_mode = 0; bool has_sph = false;
     DevBuf tri_rows, quad_rows, slab_rows, box_rows, box_face_id, box_face_rows, leaf_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
+    DevBuf tri_tight;
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
@@ -459,8 +460,10 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
                       r > 64.0 * std::max(gap, 1e-3 * r);
         SphRow row{};
         row.cx = (float)ctr.x; row.cy = (float)ctr.y; row.cz = (float)ctr.z;
-        row.r2 = (float)(r * r); row.r = (float)r; row.cn = up(norm(ctr)); row.qs = 0; row.gprim = s;
-        row.qs = is_big ? 1.0f : 0.0f;   // marks the huge spheres in the by-id table (the search rows never hold them)
+        row.r2 = (float)(r * r); row.r = (float)r; row.cn = up(norm(ctr)); row.gprim = s;
+        // how far the float32 centre lies from the true one (0 when it is representable); negative marks the huge
+        // spheres in the by-id table (the search rows never hold them)
+        row.qs = is_big ? -1.0f : up(norm(sub(ctr, V3{(double)row.cx, (double)row.cy, (double)row.cz})));
         sph_all[s] = row;
         if (is_big) big.push_back(s);
         else { sph_small.push_back(row); scene_radius = std::max(scene_radius, norm(ctr) + r); }
@@ -741,6 +744,35 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         slab_counts = (uint32_t)counts[0] | ((uint32_t)counts[1] << 10) | ((uint32_t)counts[2] << 20);
         if (!rows_slab.empty()) rows_slab.push_back(dead_slab);   // the row the loops may read ahead into
     }
+    // ---- sharper plane constants for the strict depth acceptance (see judge_tri) -------------------
+    // Per triangle (by id) and per parallelogram row (by row index): what the rounding of the row's plane to
+    // float32 and the order of its multiply-adds can cost, as coefficients of |o_x|, |o_y|, |o_z| and a constant.
+    std::vector<float> tri_tight(4 * ((size_t)d->n_tris + pair_info.size()), 0.0f);
+    {
+        const double h = (double)kU * 1.01;   // one rounding: at most u = 2^-24 of the result
+        auto put = [&](size_t slot, V3 N, double kN, const TriRow &r, double extra) {
+            const double nl = norm(N);
+            if (!std::isfinite(nl) || !(r.det_lo < INFINITY)) return;
+            const double r1 = r.nx != 0 ? 1 : 0, r2 = r.ny != 0 ? 1 : 0, tilt = extra * nl;
+            float *K = tri_tight.data() + 4 * slot;
+            K[0] = up(std::fabs(N.x - (double)r.nx) + tilt);
+            K[1] = up(h * std::fabs((double)r.ny) * r1 + std::fabs(N.y - (double)r.ny) + tilt);
+            K[2] = up(h * std::fabs((double)r.nz) * (r1 + r2) + std::fabs(N.z - (double)r.nz) + tilt);
+            K[3] = up(std::fabs(kN - (double)r.kn) + tilt * scene_radius);
+        };
+        for (int t = 0; t < d->n_tris; ++t) {
+            const double *v = d->tri_verts + 9 * (size_t)t;
+            const V3 a = {v[0], v[1], v[2]}, b = {v[3], v[4], v[5]}, cc = {v[6], v[7], v[8]};
+            const V3 N = cross(sub(b, a), sub(cc, a));
+            put((size_t)t, N, -dot(N, a), rows_all[t], 0.0);
+        }
+        // a parallelogram row stands for two triangles whose planes may differ by the 1e-11 the pairing tolerates
+        for (const PairInfo &pi : pair_info) {
+            const V3 N = cross(sub(pi.corner[1], pi.corner[0]), sub(pi.corner[2], pi.corner[0]));
+            const int row = aux[pi.tri].pair_row;
+            put((size_t)d->n_tris + (size_t)row, N, -dot(N, pi.corner[0]), rows_quad[row], 1e-10);
+        }
+    }
     // ---- materials, environment ---------------------------------------------------------------
     std::vector<MatRow> mats(d->n_objects);
     for (int i = 0; i < d->n_objects; ++i) {
@@ -796,6 +828,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     }
     HIP_TRY(c, c->box_rows.upload(box_rows)); HIP_TRY(c, c->box_face_id.upload(box_face_id)); HIP_TRY(c, c->box_face_rows.upload(box_face_rows));
     HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->slab_rows.upload(rows_slab)); HIP_TRY(c, c->leaf_rows.upload(rows_leaf)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
+    HIP_TRY(c, c->tri_tight.upload(tri_tight));
     HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
     HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));
     HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
@@ -844,6 +877,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();
     S.sph_by_id = c->sph_by_id.as<SphRow>(); S.sph_obj = c->sph_obj.as<int32_t>();
     S.materials = c->materials.as<MatRow>();
+    S.tri_tight = c->tri_tight.as<float>();
     S.leaf_rows = c->leaf_rows.as<TriRow>();
     S.bvh_nodes = use_bvh ? c->bvh.as<BvhNode>() : nullptr; S.n_bvh_nodes = use_bvh ? (int32_t)bvh_nodes.size() : 0;
     S.n_top_nodes = (d->flags & RT_SCENE_NO_LDS_TOP) ? 0 : n_top_nodes;   // switch for A/B runs
@@ -1134,10 +1168,10 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
         return fail(c, RT_ERR_INVALID_ARG, "rt_render: rectangle [%d,%d)x[%d,%d) outside %dx%d", p->x0, p->x1, p->y0, p->y1, p->width, p->height);
     if (p->sample_count < 0 || p->sample_begin < 0 || p->max_bounces < 0 || p->max_bounces > 62)
         return fail(c, RT_ERR_INVALID_ARG, "rt_render: bad sample range or max_bounces");
-    if ((p->flags & ~(uint32_t)(RT_RENDER_WAVEFRONT | RT_RENDER_STRICT_DEPTH | RT_RENDER_NO_DEFER)) != 0 || p->wavefront_paths < 0)
+    if ((p->flags & ~(uint32_t)(RT_RENDER_WAVEFRONT | RT_RENDER_STRICT_DEPTH | RT_RENDER_NO_DEFER | RT_RENDER_LOOSE_DEPTH)) != 0 || p->wavefront_paths < 0)
         return fail(c, RT_ERR_INVALID_ARG, "rt_render: unknown flag bits 0x%x or negative wavefront_paths", p->flags);
-    if ((p->flags & RT_RENDER_WAVEFRONT) && (p->flags & RT_RENDER_STRICT_DEPTH))
-        return fail(c, RT_ERR_UNSUPPORTED, "rt_render: the wavefront form has no strict-depth variant");
+    if ((p->flags & RT_RENDER_LOOSE_DEPTH) && (p->flags & (RT_RENDER_STRICT_DEPTH | RT_RENDER_WAVEFRONT)))
+        return fail(c, RT_ERR_INVALID_ARG, "rt_render: RT_RENDER_LOOSE_DEPTH goes with neither RT_RENDER_STRICT_DEPTH nor RT_RENDER_WAVEFRONT");
     float *accum = accum_dev;
     if (!accum) {
         if (c->acc_w != p->width || c->acc_h != p->height)
@@ -1193,8 +1227,8 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     // k_reduce_chunks folds everything into the buffer.  Strict depth (a tenth of the rays - every imprecise sphere
     // depth - would be set aside: measured 7.9 against 37.6 G rays/s) and RT_RENDER_NO_DEFER go straight to the full
     // kernel.  All on `stream`, no host synchronisation.
-    const bool strict = (p->flags & RT_RENDER_STRICT_DEPTH) != 0;
-    const bool lean = !strict && !(p->flags & RT_RENDER_NO_DEFER);
+    const bool strict = !(p->flags & RT_RENDER_LOOSE_DEPTH);
+    const bool lean = !(p->flags & RT_RENDER_NO_DEFER);
     const unsigned long long total_paths = (unsigned long long)rect_px * (unsigned long long)p->sample_count;
     const uint32_t aside_cap = lean ? (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(total_paths / 64, 4096), 1ull << 25) : 0;
     {
@@ -1228,20 +1262,24 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     const DevScene S = c->S;
     dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
         constexpr int TRI = decltype(T)::value; constexpr bool SPH = decltype(P)::value;
-        if (strict) { hipLaunchKernelGGL((k_render<TRI, SPH, true, false>), dim3(blocks), dim3(256), 0, stream, S, A); return; }
-        if (!lean) { hipLaunchKernelGGL((k_render<TRI, SPH, false, false>), dim3(blocks), dim3(256), 0, stream, S, A); return; }
-        hipLaunchKernelGGL((k_render<TRI, SPH, false, true>), dim3(blocks), dim3(256), 0, stream, S, A);
+        auto full = [&](unsigned grid, const RenderArgs &args) {
+            if (strict) hipLaunchKernelGGL((k_render<TRI, SPH, true, false>), dim3(grid), dim3(256), 0, stream, S, args);
+            else hipLaunchKernelGGL((k_render<TRI, SPH, false, false>), dim3(grid), dim3(256), 0, stream, S, args);
+        };
+        if (!lean) { full(blocks, A); return; }
+        if (strict) hipLaunchKernelGGL((k_render<TRI, SPH, true, true>), dim3(blocks), dim3(256), 0, stream, S, A);
+        else hipLaunchKernelGGL((k_render<TRI, SPH, false, true>), dim3(blocks), dim3(256), 0, stream, S, A);
         // the paths set aside: the full kernel's job loop over the records, one path each
         RenderArgs Q = A;
         Q.path_mode = 1; Q.job_list_count = A.aside_count; Q.job_counter = A.job_counter + 4;
 #ifdef RT_SECTION_TIMERS
         Q.prof = A.prof + kProfCount;   // (a bank of its own for the path-list launch)
 #endif
-        hipLaunchKernelGGL((k_render<TRI, SPH, false, false>), dim3(std::min(blocks, (unsigned)c->n_cu * 4)), dim3(256), 0, stream, S, Q);
+        full(std::min(blocks, (unsigned)c->n_cu * 4), Q);
         // the jobs given up: the same job loop over the list (nearly always an empty one)
         RenderArgs R = A;
         R.job_list = A.dirty_list; R.job_list_count = A.dirty_count; R.job_counter = A.job_counter + 3;
-        hipLaunchKernelGGL((k_render<TRI, SPH, false, false>), dim3(std::min(blocks, (unsigned)c->n_cu * 4)), dim3(256), 0, stream, S, R);
+        full(std::min(blocks, (unsigned)c->n_cu * 4), R);
     });
     HIP_TRY(c, hipGetLastError());
     if (n_chunks <= 256) {
@@ -1464,7 +1502,7 @@ extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *x
     A.seg_org = b_org.as<float>(); A.seg_dir = b_dir.as<float>();
     const DevScene S = c->S;
     dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
-        if (render_flags & RT_RENDER_STRICT_DEPTH)
+        if (!(render_flags & RT_RENDER_LOOSE_DEPTH))
             hipLaunchKernelGGL((k_trace_paths<decltype(T)::value, decltype(P)::value, true>),
                                dim3((unsigned)((n_paths + 255) / 256)), dim3(256), 0, 0, S, A);
         else

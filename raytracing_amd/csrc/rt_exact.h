@@ -108,6 +108,37 @@ RT_DEV double exact_tri_depth(const double *tv, D3 o, D3 d) {
     return ddot(nrm, dsub(o, pa)) * (1 / det);
 }
 
+// A sphere that is CERTAINLY hit at a known root (the float32 filter proved both) but whose float32 depth or normal
+// is not tight enough: depth, hit position and centre-to-hit vector in double precision.  Unlike the functions above
+// this is not upstream's operation sequence - it uses fused multiply-adds, and Newton steps from the float32
+// reciprocal and reciprocal-square-root estimates instead of the long division and square-root sequences - so it
+// agrees with upstream's doubles to ~1e-15 relative, not bit for bit (its results are rounded to float32 anyway).
+// Root as in sphere.py:22 / core/util.py:29-32: (-b -+ sqrt(b^2 - 4ac)) / 2a, here with b halved.
+struct SphRefined { float t, px, py, pz, qx, qy, qz; };   // q = pos - centre (length ~ radius; the caller normalises it)
+
+RT_DEV SphRefined refine_sphere64(const double *sp, D3 o, D3 d, int root) {
+    const double cx = sp[0], cy = sp[1], cz = sp[2], rad = sp[3];
+    const double rx = o.x - cx, ry = o.y - cy, rz = o.z - cz;
+    const double a = __builtin_fma(d.z, d.z, __builtin_fma(d.y, d.y, d.x * d.x));
+    const double b = __builtin_fma(rz, d.z, __builtin_fma(ry, d.y, rx * d.x));
+    const double c = __builtin_fma(rz, rz, __builtin_fma(ry, ry, __builtin_fma(rx, rx, -(rad * rad))));
+    double disc = __builtin_fma(b, b, -(a * c));
+    disc = disc > 1e-300 ? disc : 1e-300;                         // (positive for a certain hit; stay finite whatever comes)
+    double y = (double)__builtin_amdgcn_rsqf((float)disc);        // 1 / sqrt(disc): estimate, two Newton steps
+    y = y * __builtin_fma(-0.5 * (disc * y), y, 1.5);
+    y = y * __builtin_fma(-0.5 * (disc * y), y, 1.5);
+    const double s = disc * y;
+    double ia = (double)__builtin_amdgcn_rcpf((float)a);          // 1 / a likewise
+    ia = ia * __builtin_fma(-a, ia, 2.0);
+    ia = ia * __builtin_fma(-a, ia, 2.0);
+    const double t = (root ? (s - b) : (-b - s)) * ia;
+    const double px = __builtin_fma(t, d.x, o.x), py = __builtin_fma(t, d.y, o.y), pz = __builtin_fma(t, d.z, o.z);
+    SphRefined q;
+    q.t = (float)t; q.px = (float)px; q.py = (float)py; q.pz = (float)pz;
+    q.qx = (float)(px - cx); q.qy = (float)(py - cy); q.qz = (float)(pz - cz);
+    return q;
+}
+
 struct ScanHit { int32_t gprim; double t; };   // gprim < 0: miss
 
 // One primitive by global id, with its mesh's bounding-box gate.

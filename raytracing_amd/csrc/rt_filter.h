@@ -140,6 +140,9 @@ struct Ray {
     float o2;              // |o| (rounded up)
     float c4, c7;          // triangle bounds: q = c7 |t| + c4 with c4 = 4u S, c7 = 7u |d|, S = |o| + scene_radius
     float band0;           // crude per-ray discriminant bound for the in-loop sphere test
+    float rk, rko;         // a camera ray is the float32 rounding of a double-precision ray: rk = 1.01 u bounds the relative
+                           // rounding of its direction, rko = 1.01 u |o| the distance of its true origin (0 when the camera
+                           // position is representable); both 0 for every other ray
     int32_t origin;        // global id of the primitive the ray starts on, -1 = none
     // The same fact in the forms the compact rows and the box rows test it (from TriAux::tag of the origin):
     float own_idf;         // (float)(id + 1) of the first triangle of the origin's parallelogram row, 0 = the origin is in no such row
@@ -168,6 +171,8 @@ RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy
     r.c4 = 4.0f * k * Sr;
     r.c7 = 7.0f * k * r.dlen;
     r.band0 = 72.0f * kU * r.a * Sr * Sr;
+    r.rk = rounded ? 1.01f * kU : 0.0f;
+    r.rko = (rounded && (S.cam_res[0] != 0.0f || S.cam_res[1] != 0.0f || S.cam_res[2] != 0.0f)) ? 1.01f * kU * r.o2 : 0.0f;
     r.origin = origin;
     r.own_idf = (float)(tag & kTagIdMask);
     r.own_sign = u2f(0x3F800000u | (tag & kTagSecond));
@@ -340,7 +345,7 @@ RT_DEV float tri_tlo(const TriRow &T, const Ray &r, float *sure_thi) {
 constexpr int32_t kQuadFlag = 1 << 30;
 constexpr int32_t kQuadIdBits = 13;
 
-struct RowEval { float u, v, w, bb, t, thi, tlo, nd_abs; bool dead; };
+struct RowEval { float u, v, w, bb, t, thi, tlo, nd_abs, no_abs, inv_abs; bool dead; };
 
 RT_DEV RowEval row_eval(const TriRow &T, const Ray &r) {
     RowEval e;
@@ -357,7 +362,7 @@ RT_DEV RowEval row_eval(const TriRow &T, const Ray &r) {
     e.t = t;
     e.thi = fma_(g, T.ct, t);
     e.tlo = fma_(-g, T.ct, t);
-    e.nd_abs = abs_(nd);
+    e.nd_abs = abs_(nd); e.no_abs = abs_(no); e.inv_abs = abs_(inv);
     // det_lo = +inf marks the padding rows at the end of a table: never candidates (NaN included)
     e.dead = !(e.nd_abs >= T.det_lo);
     return e;
@@ -837,7 +842,27 @@ struct Verdict { int status; float t, thi; int32_t ti; bool open; float ratio; }
 // evaluated, the side of the diagonal names the triangle (Verdict::ti), and a crossing point within
 // the error band of the diagonal leaves it open (Verdict::open: both go to the double-precision
 // tie-break, scene.py:24-27).
-template <bool PAIRS>
+//
+// TIGHT (strict depth acceptance): whether the float32 depth is good enough is decided from a SHARPER error
+// bound than the row's general one.  It is used for that decision only - thi, tlo and `certain`, on which hit
+// identity rests, keep the general bounds.  With the row's plane as float32 numbers (Nf, kf), the true plane
+// (N, k) = (Nf + rho, kf + kappa) (the host knows the residues exactly), and the chains of multiply-adds of
+// row_eval, whose step j rounds its result s_j once (|e_j| <= u |s_j|, u = 2^-24; a step whose factor is zero adds
+// nothing and rounds nothing):
+//     |no_true - no| <= E_o = 3.04 u |no| + ax |ox| + ay |oy| + az |oz| + ak
+//     |nd_true - nd| <= E_d = 3.04 u |nd| + ax |dx| + ay |dy| + az |dz|
+// with ax = |rho_x|, ay = u |Nf_y| [Nf_x != 0] + |rho_y|, az = u |Nf_z| ([Nf_x != 0] + [Nf_y != 0]) + |rho_z|,
+// ak = |kappa| (from |s_1| <= |s_3| + |Nf_z o_z| + |Nf_y o_y|, |s_2| <= |s_3| + |Nf_z o_z|); a camera ray, which is
+// the rounding of a double-precision ray, adds u |N| |o| (Ray::rko) and u |N| |d| (Ray::rk).  For a wall whose plane is
+// perpendicular to an axis with representable coordinates all four constants are zero: its depth carries a few u
+// however the ray grazes it.  Then
+//     |t_true - t| <= (E_o + |t| E_d) / (|nd| - E_d) + 3 u |t|       (rcp within 1 ulp = 2 u, one product)
+// and 1 / (|nd| - E_d) <= (1 + 2 x) / |nd| for x = E_d / |nd| <= 1/4.  Upstream's own double-precision roundings
+// (1e-16 of the same expression) and the 1e-11 by which the two triangles of a parallelogram row may leave a
+// common plane (folded into the row's constants by the host) are far below the acceptance threshold.
+constexpr float kTightChain = 3.04f * kU;
+
+template <bool PAIRS, bool TIGHT>
 RT_DEV Verdict judge_tri(SceneRef S, int32_t ti, const Ray &r, float rel_accept, float abs_accept) {
     const TriAux X = S.tri_aux[ti];
     const bool pair = PAIRS && X.pair_row >= 0;
@@ -864,16 +889,45 @@ RT_DEV Verdict judge_tri(SceneRef S, int32_t ti, const Ray &r, float rel_accept,
         const float off = fma_(bt, r.dlen, r.c4) * T.cb;
         v.ratio = mu > 0.0f ? off * rcp_(room) : kInf;
     }
-    v.status = !certain ? 2 : ((bt <= max_(rel_accept * e.t, abs_accept)) ? 0 : 1);
+    float bt_accept = bt;
+    if (TIGHT) {
+        const f4 K = *(const f4 *)(S.tri_tight + 4 * (size_t)(pair ? (S.n_prims - S.n_spheres) + X.pair_row : ti));
+        const float cam = r.rk * T.ct;
+        const float eo = fma_(T.ct, r.rko, fma_(K.z, abs_(r.oz), fma_(K.y, abs_(r.oy), fma_(K.x, abs_(r.ox), fma_(kTightChain, e.no_abs, K.w)))));
+        const float ed = fma_(cam, r.dlen, fma_(K.z, abs_(r.dz), fma_(K.y, abs_(r.dy), fma_(K.x, abs_(r.dx), kTightChain * e.nd_abs))));
+        const float x = ed * e.inv_abs;
+        const float q = fma_(abs_(e.t), ed, eo) * e.inv_abs;
+        const float bt2 = fma_(q, fma_(2.0f, x, 1.01f), 3.1f * kU * abs_(e.t));
+        bt_accept = (x <= 0.25f) ? min_(bt, bt2) : bt;   // (a NaN fails the compare and leaves the general bound)
+    }
+    v.status = !certain ? 2 : ((bt_accept <= max_(rel_accept * e.t, abs_accept)) ? 0 : 1);
     return v;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Small spheres
 // ---------------------------------------------------------------------------------------------
-struct SphBounds { float t1lo, t1hi, t2lo, t2hi, b, eb; bool maybe, surely; float t1, t2; };
+struct SphBounds { float t1lo, t1hi, t2lo, t2hi, b, eb; bool maybe, surely; float t1, t2; float et, cam; };   // et, cam: see sphere_bounds (TIGHT)
 
 // Bounds on both roots from the cancellation-free form (t - tc)^2 = (r^2 - |ro + tc d|^2) / a.
+//
+// TIGHT (strict depth acceptance) adds `et`, a SHARPER bound on |t - t_true| of either root, used only to decide
+// whether the float32 depth and normal are good enough; identity rests on the general bounds as before.  With
+// l = ro + tc d the foot of the perpendicular from the centre (so l . d = 0 for the true values):
+//   * E_ro = |ro - ro_true| <= u |ro| (nothing when c = 0: then ro = o) + |c - c_true| (SphRow::qs)
+//            + u (|o| [unless the camera position is representable] + |ro| + r) for a camera ray, whose true ray
+//            passes that far from the float32 one near the sphere   (u = 2^-24 bounds one rounding);
+//   * b = ro . d: three rounded multiply-adds, |b - b_true| <= E_b = (3.04 u |ro| + E_ro) |d|;
+//   * tc = -b rcp(a): E_tc = E_b / a + 6.1 u |tc|   (a = d . d is a sum of squares: 3 u; rcp 1 ulp = 2 u; one product);
+//   * an error of tc moves l ALONG d, at right angles to l, so it enters |l|^2 only squared; an error of ro enters
+//     with 2 |l| E_ro <= 2 r E_ro (the ray hits: |l| <= r); the roundings of l (one fused multiply-add per
+//     component), of the sum of squares, of r^2 in the table and of the subtraction are each relative:
+//     |h2 - h2_true| <= E_h = 7.2 u r^2 + 2.02 r E_ro + 1.01 (E_tc |d| + E_ro)^2;
+//   * s = sqrt(h2 / a): E_s = E_h / (a s) + 5.6 u s   (|sqrt(x + e) - sqrt(x)| <= |e| / sqrt(x));
+//   * t = tc -+ s: et = E_tc + E_s + u (|tc| + s), plus 2 u (|tc| + s) for a camera ray (its direction's rounding
+//     rescales the depth).
+// For the room's sphere (c = 0, r = 1/2) that is about 20 u where the general bound gives 35 to 80 u.
+template <bool TIGHT = false>
 RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
     SphBounds o;
     float rox = r.ox - P.cx, roy = r.oy - P.cy, roz = r.oz - P.cz;
@@ -901,6 +955,19 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
     o.t2lo = tc + slo - eb; o.t2hi = tc + shi + eb;
     o.t1 = tc - smid; o.t2 = tc + smid;
     o.b = b; o.eb = ebb;
+    o.et = kInf; o.cam = 0.0f;
+    if (TIGHT) {
+        const float kro = P.cn > 0.0f ? 1.01f * kU : 0.0f;
+        o.cam = fma_(r.rk, mlen + P.r, r.rko);
+        const float e_ro = fma_(kro, mlen, P.qs) + o.cam;
+        const float e_b = fma_(3.04f * kU, mlen, e_ro) * r.dlen;
+        const float reach = abs_(tc) + smid;
+        const float e_tc = fma_(e_b, r.inv_a * 1.001f, 6.1f * kU * abs_(tc));
+        const float w = fma_(e_tc, r.dlen, e_ro);
+        const float e_h = fma_(7.2f * kU, P.r2, fma_(2.02f * P.r, e_ro, 1.01f * w * w));
+        const float e_s = fma_(e_h * r.inv_a, rcp_(smid) * 1.01f, 5.6f * kU * smid);
+        o.et = e_tc + e_s + fma_(2.0f, r.rk, 1.01f * kU) * reach;   // (smid = 0: inf or NaN, never "precise")
+    }
     return o;
 }
 
@@ -950,6 +1017,7 @@ RT_DEV void search_big_spheres(SceneRef S, const Ray &r, D3 o64, D3 d64, Sink &s
 
 struct SphVerdict { int status; int root; float t, thi; };
 
+template <bool TIGHT = false>
 RT_DEV SphVerdict sphere_verdict(const SphRow &P, const SphBounds &o, int32_t si, const Ray &r, float rel_accept, float abs_accept) {
     SphVerdict v; v.status = 2; v.root = 0; v.t = 0; v.thi = 0;
     float lo, hi, t; int root; bool certain;
@@ -968,13 +1036,21 @@ RT_DEV SphVerdict sphere_verdict(const SphRow &P, const SphBounds &o, int32_t si
     float half = 0.5f * (hi - lo);
     float perr = half * r.dlen + 3.0f * kU * (r.o2 + P.cn + t * r.dlen) * 1.75f;
     bool precise = (half <= max_(rel_accept * t, abs_accept)) && (perr <= rel_accept * P.r);
+    if (TIGHT) {
+        // the hit position o + t d lies on the sphere: |pos| <= |c| + r; it is off by et |d|, its own rounding (u |pos|),
+        // a camera ray's distance from its float32 rounding, and the normal (pos - c) / r also by the centre's rounding
+        // and by ~8 u of its own arithmetic
+        const float perr2 = fma_(o.et, r.dlen, fma_(1.01f * kU, P.cn + 1.01f * P.r, P.qs)) + fma_(8.5f * kU, P.r, o.cam);
+        precise = precise || ((o.et <= max_(rel_accept * t, abs_accept)) && (perr2 <= rel_accept * P.r));
+    }
     v.status = precise ? 0 : 1;
     return v;
 }
 
+template <bool TIGHT = false>
 RT_DEV SphVerdict judge_sphere(SceneRef S, int32_t si, const Ray &r, float rel_accept, float abs_accept) {
     const SphRow P = S.sph_by_id[si];
-    return sphere_verdict(P, sphere_bounds(P, r), si, r, rel_accept, abs_accept);
+    return sphere_verdict<TIGHT>(P, sphere_bounds<TIGHT>(P, r), si, r, rel_accept, abs_accept);
 }
 
 // Scenes with one or two small spheres: the search loop's cheap discriminant test followed by the
@@ -984,20 +1060,20 @@ RT_DEV SphVerdict judge_sphere(SceneRef S, int32_t si, const Ray &r, float rel_a
 constexpr int kFewSpheres = 2;
 struct SpherePre { int32_t id; float tl; SphVerdict v; };
 
-template <class Sink>
+template <bool TIGHT, class Sink>
 RT_DEV void search_few_spheres(SceneRef S, const Ray &r, Sink &sink, SpherePre &pre, float rel_accept, float abs_accept) {
     const int n = S.n_sph_rows;
     const SphRow *rows = S.sph_rows;
     for (int i = 0; i < n; ++i) {
         const SphRow P = load_sph_row_uniform(rows, i);
-        const SphBounds o = sphere_bounds(P, r);
+        const SphBounds o = sphere_bounds<TIGHT>(P, r);
         const bool own = P.gprim == r.origin;
         // candidate exactly when the cheap test would have one: possibly touched, and the root that counts may lie ahead
         const bool valid = o.maybe && (own ? (o.b < o.eb) : (o.t2hi > 0.0f));
         float tl = own ? o.t2lo : (o.t1hi < 0.0f ? o.t2lo : o.t1lo);
         tl = valid ? max_(tl, 0.0f) * (1.0f - 8.0f * kU) : kInf;
         sink(tl, P.gprim);
-        if (tl < pre.tl) { pre.tl = tl; pre.id = P.gprim; pre.v = sphere_verdict(P, o, P.gprim, r, rel_accept, abs_accept); }
+        if (tl < pre.tl) { pre.tl = tl; pre.id = P.gprim; pre.v = sphere_verdict<TIGHT>(P, o, P.gprim, r, rel_accept, abs_accept); }
     }
 }
 
@@ -1086,12 +1162,12 @@ RT_DEV int ray_route(const Ray &r) {
 template <int TRI> struct FirstPass { typedef typename std::conditional<TRI == kTriBvh, PairBest, KeyBest<TRI == kTriBrute>>::type type; };
 
 // First pass without the hierarchy walk: spheres and the linear tables.
-template <int TRI, bool HAS_SPH>
+template <int TRI, bool HAS_SPH, bool STRICT = false>
 RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename FirstPass<TRI>::type &first,
                       SpherePre *pre = nullptr, float rel_accept = 0.0f, float abs_accept = 0.0f) {
     first.init(S);
     if (HAS_SPH) {
-        if (pre != nullptr && S.n_sph_rows <= kFewSpheres) search_few_spheres(S, r, first, *pre, rel_accept, abs_accept);
+        if (pre != nullptr && S.n_sph_rows <= kFewSpheres) search_few_spheres<STRICT>(S, r, first, *pre, rel_accept, abs_accept);
         else search_spheres(S, r, first);
         PROF(kProfSpheres);
         if (S.n_big_sph > 0) {
@@ -1140,7 +1216,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         if (box_open) {
             gprim = -1;
         } else if (gprim < S.n_spheres) {
-            if (HAS_SPH && S.n_big_sph > 0 && S.sph_by_id[gprim].qs != 0.0f) {
+            if (HAS_SPH && S.n_big_sph > 0 && S.sph_by_id[gprim].qs < 0.0f) {
                 // a huge sphere: its depth is exact already (double precision, as in the search loop);
                 // position and normal follow in float32 like any other hit's (|pos - c| / r is good
                 // to ~1e-7 however large r is)
@@ -1150,11 +1226,11 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
             } else {
                 SphVerdict v;
                 if (pre != nullptr && pre->id == gprim) v = pre->v;   // worked out in the first pass already
-                else v = judge_sphere(S, gprim, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
+                else v = judge_sphere<STRICT>(S, gprim, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
                 status = v.status; t = v.t; thi = v.thi; root = v.root;
             }
         } else {
-            const Verdict v = judge_tri<!FirstPass<TRI>::type::kPerTriangle>(S, gprim - S.n_spheres, r,
+            const Verdict v = judge_tri<!FirstPass<TRI>::type::kPerTriangle, STRICT>(S, gprim - S.n_spheres, r,
                                                                              STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
             status = v.status; t = v.t; thi = v.thi; gprim = S.n_spheres + v.ti; pair_open = v.open; h.own_ratio = v.ratio;
         }
@@ -1162,6 +1238,10 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
     PROF(kProfJudge);
     const bool settle = route != kRouteFilter || box_open || (gprim >= 0 && (status != 0 || (has_second && !(second_lo > thi))));
     ExactHit e; e.hit = false; e.prim = 0; e.t = 0; e.n = d3(0, 0, 0); e.pos = e.n;
+    // a small sphere, certainly hit at root `root`, whose float32 depth or normal was not tight enough: redone in
+    // double precision by refine_sphere64 (the hit record below takes position and normal from it)
+    bool sph_refined = false;
+    SphRefined sref; sref.t = 0; sref.px = sref.py = sref.pz = 0; sref.qx = sref.qy = sref.qz = 0;
     if (DEFER) {
         // The kernel this is compiled into holds none of the settling code: a query the float32 code cannot
         // answer alone is handed back unanswered (how == kHowDeferred), and the caller sets the whole path aside
@@ -1172,9 +1252,10 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         // same position - 47 % of the room's hand-backs - was tried inline too: half as many paths set aside, but the
         // double-precision sphere code slows the lean kernel by as much as the full kernel saves.)
         bool hand_back = settle;
-        if (settle && route == kRouteFilter && !box_open && !pair_open && gprim >= S.n_spheres && status == 1) {
+        if (settle && route == kRouteFilter && !box_open && !pair_open && status == 1) {
             const Ray64 x64 = ray64(r, rr);
-            t = (float)exact_tri_depth(S.cold->tri64 + 9 * (size_t)(gprim - S.n_spheres), x64.o, x64.d);
+            if (gprim >= S.n_spheres) t = (float)exact_tri_depth(S.cold->tri64 + 9 * (size_t)(gprim - S.n_spheres), x64.o, x64.d);
+            else { sref = refine_sphere64(S.cold->sph64 + 4 * (size_t)gprim, x64.o, x64.d, root); t = sref.t; sph_refined = true; }
             thi = t * (1.0f + 2.0f * kU);
             h.refined = true; h.how = 1;
             hand_back = has_second && !(second_lo > thi);
@@ -1204,7 +1285,12 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
                 t = (float)exact_tri_depth(S.cold->tri64 + 9 * (size_t)(gprim - S.n_spheres), o64, d64);
                 thi = t * (1.0f + 2.0f * kU);
                 h.how = 1;
-            } else if (status != 0) {   // undecided, or an imprecise sphere: double precision for this primitive
+            } else if (status == 1) {   // a sphere that is certainly the hit, at a known root: depth, position and normal redone
+                h.refined = true;
+                sref = refine_sphere64(S.cold->sph64 + 4 * (size_t)gprim, o64, d64, root); sph_refined = true;
+                t = sref.t; thi = t * (1.0f + 2.0f * kU);
+                h.how = 1;
+            } else if (status != 0) {   // undecided: double precision for this primitive
                 h.refined = true;
                 e = exact_single(S, gprim, o64, d64, r.origin);
                 if (e.hit) { t = (float)e.t; thi = t * (1.0f + 2.0f * kU); root = e.prim; }
@@ -1260,6 +1346,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         const SphRow P = S.sph_by_id[gprim];
         float ir = rcp_(P.r);
         float nx = (h.px - P.cx) * ir, ny = (h.py - P.cy) * ir, nz = (h.pz - P.cz) * ir;
+        if (sph_refined) { h.px = sref.px; h.py = sref.py; h.pz = sref.pz; nx = sref.qx * ir; ny = sref.qy * ir; nz = sref.qz * ir; }
         float s = rsq_(fma_(nz, nz, fma_(ny, ny, nx * nx)));
         h.nx = nx * s; h.ny = ny * s; h.nz = nz * s;
     } else {
@@ -1281,7 +1368,7 @@ RT_DEV Hit closest_hit(SceneRef S, const Ray &r, ExactHit *e64, const RayResidue
     // with the same bounds, so that both settle the same queries and every path comes out bit for bit the same)
     constexpr bool kUsePre = HAS_SPH && TRI != kTriBvh;
     if (ray_route<TRI>(r) == kRouteFilter) {
-        hit_begin<TRI, HAS_SPH>(S, r, rr, first, kUsePre ? &pre : nullptr, STRICT ? kRelAcceptStrict : kRelAcceptRender,
+        hit_begin<TRI, HAS_SPH, STRICT>(S, r, rr, first, kUsePre ? &pre : nullptr, STRICT ? kRelAcceptStrict : kRelAcceptRender,
                                 STRICT ? 0.0f : kAbsAcceptRender * (r.o2 + S.scene_radius));
         if (TRI == kTriBvh) { int node = 0; search_bvh(S, r, first, bc, node, 0x7FFFFFFF); }
     }

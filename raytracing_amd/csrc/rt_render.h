@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void k_raytrace(const DevScene S_arg, const Ra
         if (p.depth <= A.max_bounces) {   // renderer.py:29-30
             for (;;) {
                 const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, false, p.tag, p.own_ratio);
-                const Hit h = closest_hit<TRI, HAS_SPH, false>(S, ray, nullptr, no_residue());
+                const Hit h = closest_hit<TRI, HAS_SPH, true>(S, ray, nullptr, no_residue());
                 rays++;
                 if (h.obj < 0) sky++; else shaded++;
                 uint32_t sky_unused = 0;

@@ -80,7 +80,8 @@ struct TriAux {
 // One small sphere, 8 dwords = one s_load_dwordx8.
 struct SphRow {
     float cx, cy, cz, r2;
-    float qs;        // discriminant error bound = a * (kBandM2 * |ro|^2 + qs)
+    float qs;        // >= 0: |c - c_true|, how far the float32 centre lies from the double-precision one (0 when it is exact);
+                     // < 0 (by-id table only): a huge sphere, evaluated in double precision
     float cn;        // |c|, for the bound on ro.d
     float r;
     int32_t gprim;   // = sphere index
@@ -162,6 +163,9 @@ struct DevScene {
     const BvhNode *bvh_nodes; int32_t n_bvh_nodes;    // threaded hierarchy over leaf_rows: 8 copies of n_bvh_nodes nodes, one per
                                                       // ray-direction octant, each with its top levels first; 0 = none
     int32_t n_top_nodes;                              // per copy, the first n_top_nodes nodes are the top levels (staged in LDS)
+    // Per plane, what the float32 row's rounding and the order of its multiply-adds can cost: four floats (ax, ay, az, ak)
+    // per triangle (by triangle id), then per parallelogram row (by row index).  See judge_tri.
+    const float *tri_tight;
 };
 static_assert(offsetof(DevScene, tri_aux) == 64 && offsetof(DevScene, cam_pos) == 128, "DevScene: the two hot runs are 16 dwords each");
 

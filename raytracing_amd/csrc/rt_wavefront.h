@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, cons
             if (walk_node >= 0) search_bvh(S, r, first, bc, walk_node, kWfSlice);
             if (walk_node < 0) {
                 BvhCounters second_pass = bc; second_pass.nodes = 0; second_pass.tris = 0;
-                const Hit h = hit_finish<TRI, HAS_SPH, false>(S, r, rr, first, second_pass, nullptr);
+                const Hit h = hit_finish<TRI, HAS_SPH, true>(S, r, rr, first, second_pass, nullptr);
                 bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
                 WfHit w;
                 w.nx = h.nx; w.ny = h.ny; w.nz = h.nz; w.obj = h.obj;

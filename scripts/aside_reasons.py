@@ -1,5 +1,5 @@
 """Why the lean kernel sets paths aside (developer tool; needs a library built with -DRT_ASIDE_REASONS:
-    RAYTRACING_AMD_LIB=build_ab/_rt_reasons.so python scripts/aside_reasons.py [room|horse6] [spp])."""
+    RAYTRACING_AMD_LIB=variants/_rt_reasons.so python scripts/aside_reasons.py [room|horse6] [spp])."""
 import ctypes as C, os, sys, dataclasses
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))

@@ -134,7 +134,7 @@ def test_library_exports_every_declared_symbol():
     handle = rtlib.load_library()
     for name in declared:
         assert hasattr(handle, name), name
-    assert handle.rt_abi_version() == 2
+    assert handle.rt_abi_version() == 3
     assert C.sizeof(rtlib.RtRenderParams) == 56
 
 
