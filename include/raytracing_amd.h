@@ -258,6 +258,10 @@ int rt_synchronize(rt_ctx *ctx, void *stream);
  *                       asynchronous on `stream`; every rank must call it with the same size.
  * librccl.so is opened on first use; RT_ERR_UNSUPPORTED when it cannot be. */
 #define RT_COMM_ID_BYTES 128
+/* RT_OK when librccl.so can be opened and holds what rt_comm_* need, RT_ERR_UNSUPPORTED otherwise (reason:
+ * rt_last_error(NULL)).  No upstream counterpart; needs no context and no GPU.  Lets every rank find out
+ * BEFORE the collective rt_comm_init whether all of them can enter it. */
+int rt_comm_available(void);
 int rt_comm_unique_id(void *out_128_bytes);
 int rt_comm_init(rt_ctx *ctx, int32_t n_ranks, int32_t rank, const void *unique_id_128_bytes);
 int rt_merge(rt_ctx *ctx, float *accum_dev, int32_t width, int32_t height, void *stream);

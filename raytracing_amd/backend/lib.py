@@ -23,7 +23,7 @@ RT_ERR_STOPPED = 5
 # every symbol include/raytracing_amd.h declares
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
-           "rt_comm_unique_id", "rt_comm_init", "rt_merge",
+           "rt_comm_available", "rt_comm_unique_id", "rt_comm_init", "rt_merge",
            "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms", "rt_debug_scene_layout", "rt_debug_render_counters",
            "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_build_bvh_threads", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
@@ -240,6 +240,12 @@ class HipBackend:
         if st != 0:
             raise BackendError(st, (lib.rt_last_error(None) or b"").decode())
         return buf.raw
+
+    @staticmethod
+    def comm_ready() -> bool:
+        """Whether this process can open RCCL at all (``rt_comm_available``): asked on every rank before the
+        collective ``comm_init``, so that no rank enters it alone."""
+        return load_library().rt_comm_available() == 0
 
     def comm_init(self, n_ranks: int, rank: int, unique_id: Optional[bytes] = None) -> None:
         buf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), 128)

@@ -918,10 +918,10 @@ namespace {
 // (Re)build the camera-ray table for width x height on `stream` if the cached one does not match.
 int ensure_ray_table(rt_ctx *c, int width, int height, hipStream_t stream) {
     if (c->ray_w == width && c->ray_h == height) return RT_OK;
-    const size_t bytes = (size_t)width * height * 4 * sizeof(float);
-    if (bytes > c->ray_dir.bytes || bytes > c->ray_res.bytes) {
+    const size_t bytes = (size_t)width * height * 4 * sizeof(float);   // directions: four floats; residues: four doubles per pixel
+    if (bytes > c->ray_dir.bytes || 2 * bytes > c->ray_res.bytes) {
         HIP_TRY(c, hipDeviceSynchronize());   // earlier launches may still read the old tables
-        HIP_TRY(c, c->ray_dir.ensure(bytes)); HIP_TRY(c, c->ray_res.ensure(bytes));
+        HIP_TRY(c, c->ray_dir.ensure(bytes)); HIP_TRY(c, c->ray_res.ensure(2 * bytes));
     }
     hipLaunchKernelGGL(k_raygen, dim3((unsigned)(((size_t)width * height + 255) / 256)), dim3(256), 0, stream, c->S, width, height,
                        c->ray_dir.as<float>(), c->ray_res.as<float>());
@@ -1305,6 +1305,12 @@ namespace {
 }  // namespace
 
 extern "C" {
+
+int rt_comm_available(void) {
+    Rccl &r = rccl();
+    if (!r.handle) return fail(nullptr, RT_ERR_UNSUPPORTED, "%s", r.why.c_str());
+    return RT_OK;
+}
 
 int rt_comm_unique_id(void *out_128_bytes) {
     if (!out_128_bytes) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_comm_unique_id: NULL argument");

@@ -1098,15 +1098,16 @@ struct Hit {
 
 // The exact code's view of a ray.  Bounce rays and caller-supplied rays ARE their float32 values.
 // A pinhole camera ray is the float32 rounding of the ray upstream computes in double precision
-// (camera.py:39-42); k_raygen keeps the rounding residue (double - float32, as a float32) per pixel,
-// and the exact code adds it back, so that camera rays which graze an edge - with a 90 degree
-// field of view the image diagonals of the room scene run exactly along the cube's edges - resolve
-// as upstream resolves them.  `table` is null for every other ray.
-// `table` and the origin residue are the same for every lane (kernel arguments); only `on` and
-// `pixel` are per-lane, and both already live in the caller's state.
-struct RayResidue { const float *table; uint32_t pixel; bool on; float ox, oy, oz; };
+// (camera.py:39-42); k_raygen keeps, per pixel, the rounding residue of the direction as DOUBLES (double - float32
+// is exact in double precision), and the exact code adds it back and starts from the camera's double-precision
+// position: it then sees upstream's very doubles, so that camera rays which graze an edge - with a 90 degree
+// field of view the image diagonals of the room scene run exactly along the cube's edges - resolve as upstream
+// resolves them, cracks between walls included.  `table` is null for every other ray.
+// `table` is the same for every lane (a kernel argument); only `on` and `pixel` are per-lane, and both already
+// live in the caller's state.
+struct RayResidue { const float *table; uint32_t pixel; bool on; };   // table: four doubles per pixel (x, y, z, unused)
 
-RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r.on = false; r.ox = r.oy = r.oz = 0.0f; return r; }
+RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r.on = false; return r; }
 
 // How the triangles of a scene are searched.
 enum { kTriNone = 0, kTriBrute = 1, kTriBvh = 2 };
@@ -1131,17 +1132,18 @@ RT_DEV void exact_scan_pass(SceneRef S, D3 o64, D3 d64, int32_t origin, ExactHit
 
 struct Ray64 { D3 o, d; };
 
-// The ray the exact code sees: the float32 ray plus, for a pinhole camera ray, its residue.
-RT_DEV Ray64 ray64(const Ray &r, const RayResidue rr) {
+// The ray the exact code sees: the float32 ray, or for a pinhole camera ray upstream's doubles.
+RT_DEV Ray64 ray64(SceneRef S, const Ray &r, const RayResidue rr) {
     // only rare double-precision branches read these; the loads and conversions sink into them
-    float rdx = 0.0f, rdy = 0.0f, rdz = 0.0f, rox = 0.0f, roy = 0.0f, roz = 0.0f;
-    if (rr.on) {
-        const f4 q = *(const f4 *)(rr.table + 4 * (size_t)rr.pixel);
-        rdx = q.x; rdy = q.y; rdz = q.z; rox = rr.ox; roy = rr.oy; roz = rr.oz;
-    }
     Ray64 x;
-    x.o = d3((double)r.ox + (double)rox, (double)r.oy + (double)roy, (double)r.oz + (double)roz);
-    x.d = d3((double)r.dx + (double)rdx, (double)r.dy + (double)rdy, (double)r.dz + (double)rdz);
+    x.o = d3((double)r.ox, (double)r.oy, (double)r.oz);
+    x.d = d3((double)r.dx, (double)r.dy, (double)r.dz);
+    if (rr.on) {
+        const double *q = (const double *)rr.table + 4 * (size_t)rr.pixel;
+        const double *cam = S.cold->cam64;
+        x.o = d3(cam[0], cam[1], cam[2]);
+        x.d = d3(x.d.x + q[0], x.d.y + q[1], x.d.z + q[2]);
+    }
     return x;
 }
 
@@ -1171,7 +1173,7 @@ RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename Fi
         else search_spheres(S, r, first);
         PROF(kProfSpheres);
         if (S.n_big_sph > 0) {
-            const Ray64 x = ray64(r, rr);
+            const Ray64 x = ray64(S, r, rr);
             search_big_spheres(S, r, x.o, x.d, first);
         }
         PROF(kProfBigSpheres);
@@ -1220,7 +1222,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
                 // a huge sphere: its depth is exact already (double precision, as in the search loop);
                 // position and normal follow in float32 like any other hit's (|pos - c| / r is good
                 // to ~1e-7 however large r is)
-                const Ray64 x = ray64(r, rr);
+                const Ray64 x = ray64(S, r, rr);
                 const ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)gprim, x.o, x.d, gprim == r.origin, false);
                 status = eb.hit ? 0 : 2; t = (float)eb.t; thi = t * (1.0f + 2.0f * kU); root = eb.prim;
             } else {
@@ -1253,7 +1255,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         // double-precision sphere code slows the lean kernel by as much as the full kernel saves.)
         bool hand_back = settle;
         if (settle && route == kRouteFilter && !box_open && !pair_open && status == 1) {
-            const Ray64 x64 = ray64(r, rr);
+            const Ray64 x64 = ray64(S, r, rr);
             if (gprim >= S.n_spheres) t = (float)exact_tri_depth(S.cold->tri64 + 9 * (size_t)(gprim - S.n_spheres), x64.o, x64.d);
             else { sref = refine_sphere64(S.cold->sph64 + 4 * (size_t)gprim, x64.o, x64.d, root); t = sref.t; sph_refined = true; }
             thi = t * (1.0f + 2.0f * kU);
@@ -1269,7 +1271,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         }
     }
     if (!DEFER && settle) {
-        const Ray64 x64 = ray64(r, rr);
+        const Ray64 x64 = ray64(S, r, rr);
         const D3 o64 = x64.o, d64 = x64.d;
         const bool scan = route == kRouteScan;
         bool second = route == kRouteOpen; float limit = kInf;

@@ -118,8 +118,8 @@ RT_DEV double rsqrt64(double x) {
 // Ray generation: Camera.get_ray's pinhole part (camera.py:40) for every pixel of a W x H image
 // (renderer.py:96-103), in double precision and in upstream's exact operation order - sqrt and
 // divisions included, so the doubles are bit-identical to upstream's.  Writes, per pixel
-// (x * H + y), the float32 direction and the residue double - float32.  Runs once per
-// (camera, W, H); the render kernel only loads from the table.
+// (x * H + y), the float32 direction (16 bytes) and the residue double - float32 as three doubles
+// (32 bytes).  Runs once per (camera, W, H); the render kernel only loads from the table.
 __global__ __launch_bounds__(256) void k_raygen(const DevScene S_arg, int W, int H, float *ray_dir, float *ray_res) {
     SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,9 +133,9 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene S_arg, int W, int
     const D3 d = dnormalize(t);
     const float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
     f4 dir; dir.x = fx; dir.y = fy; dir.z = fz; dir.w = 0.0f;
-    f4 res; res.x = (float)(d.x - (double)fx); res.y = (float)(d.y - (double)fy); res.z = (float)(d.z - (double)fz); res.w = 0.0f;
     *(f4 *)(ray_dir + 4 * (size_t)i) = dir;
-    *(f4 *)(ray_res + 4 * (size_t)i) = res;
+    double *res = (double *)ray_res + 4 * (size_t)i;   // (double - float32: exact in double precision)
+    res[0] = d.x - (double)fx; res[1] = d.y - (double)fy; res[2] = d.z - (double)fz; res[3] = 0.0;
 }
 
 // Camera ray of one path.  Pinhole cameras: the table entry.  Depth of field (camera.py:43-49): the
@@ -149,8 +149,8 @@ RT_DEV void camera_ray(SceneRef S, const float *ray_dir, const float *ray_res, u
     ox = S.cam_pos[0]; oy = S.cam_pos[1]; oz = S.cam_pos[2];
     if (S.dof_on) {
         const double *c = S.cold->cam64;
-        const f4 e = *(const f4 *)(ray_res + 4 * (size_t)pixel);
-        const double ddx = (double)q.x + (double)e.x, ddy = (double)q.y + (double)e.y, ddz = (double)q.z + (double)e.z;
+        const double *e = (const double *)ray_res + 4 * (size_t)pixel;
+        const double ddx = (double)q.x + e[0], ddy = (double)q.y + e[1], ddz = (double)q.z + e[2];
         const Draws dr = segment_draws(key0, key1, 0);
         const double j1 = ((double)dr.f0 * 2 - 1) * c[13], j2 = ((double)dr.f1 * 2 - 1) * c[13];
         const double gx = ddx * c[14] + c[0], gy = ddy * c[14] + c[1], gz = ddz * c[14] + c[2];
@@ -236,7 +236,6 @@ RT_DEV RayResidue path_residue(SceneRef S, const float *ray_res, const Path &p) 
     // a pinhole camera ray is the rounding of a double-precision ray whose residue is in the table
     RayResidue rr;
     rr.table = ray_res; rr.pixel = p.pixel; rr.on = (p.depth == 0) && !S.dof_on;
-    rr.ox = S.cam_res[0]; rr.oy = S.cam_res[1]; rr.oz = S.cam_res[2];
     return rr;
 }
 

@@ -143,7 +143,6 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, cons
             const Ray r = make_ray(S, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, ray.origin, depth == 0, origin_tag(S, ray.origin));
             RayResidue rr;
             rr.table = A.ray_res; rr.pixel = pixel; rr.on = (depth == 0) && !S.dof_on;
-            rr.ox = S.cam_res[0]; rr.oy = S.cam_res[1]; rr.oz = S.cam_res[2];
             if (!walking) {
                 walking = true;
                 walk_node = -1;

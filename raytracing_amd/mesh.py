@@ -70,6 +70,8 @@ class Mesh(ObjectBase):
     integer array-like indexing ``vertices``.
     """
 
+    _warned_no_native_reader = False   # the fallback to the Python OBJ parser is announced once per process
+
     def __init__(self, material: Material, origin: Vec3, vertices, triangles,
                  scale: Vec3 | None = None, rotation: Vec3 | None = None) -> None:
         super().__init__(material, origin)
@@ -215,7 +217,13 @@ class Mesh(ObjectBase):
             from .backend.lib import load_library
 
             lib = load_library()
-        except Exception:
+        except Exception as e:   # noqa: BLE001 - the pure-Python reader gives the same result, some thirty times slower
+            if not Mesh._warned_no_native_reader:
+                import warnings
+
+                Mesh._warned_no_native_reader = True
+                warnings.warn(f"raytracing_amd: the native OBJ reader is unavailable ({e!r}); falling back to the "
+                              "Python parser, which is about 30 times slower on large files", RuntimeWarning, stacklevel=3)
             return None
         handle = C.c_void_p()
         n_obj, n_v, n_t = C.c_int32(0), C.c_int64(0), C.c_int64(0)

@@ -86,14 +86,23 @@ class FakeCommBackend(FakeBackend):
     """A backend that brings its own communicator, as HipBackend does (rt_comm_init / rt_merge):
     here the "library" all-reduce is gloo's, so the hand-shake around it can be checked on CPU."""
     fail_on_rank = None
+    fail_where = "comm_init"     # or "unique_id" (rank 0 cannot make the id) or "ready" (a rank cannot open the library)
+    entered_init = False
 
     @staticmethod
     def comm_unique_id():
+        if FakeCommBackend.fail_where == "unique_id" and FakeCommBackend.fail_on_rank == 0:
+            raise RuntimeError("cannot open librccl.so")
         return bytes(range(128))
 
+    def comm_ready(self):
+        return not (FakeCommBackend.fail_where == "ready" and dist.get_rank() == FakeCommBackend.fail_on_rank)
+
     def comm_init(self, n_ranks, rank, unique_id):
-        if rank == FakeCommBackend.fail_on_rank:
+        FakeCommBackend.entered_init = True
+        if FakeCommBackend.fail_where == "comm_init" and rank == FakeCommBackend.fail_on_rank:
             raise RuntimeError("no RCCL here")
+        assert unique_id == bytes(range(128))
         self.comm = (n_ranks, rank, unique_id)
 
     def merge(self, width, height, accum_ptr=0, stream=0):
@@ -102,10 +111,11 @@ class FakeCommBackend(FakeBackend):
         dist.all_reduce(self.accum)
 
 
-def _comm_worker(rank, world, port, out_dir, fail_on_rank):
+def _comm_worker(rank, world, port, out_dir, fail_on_rank, fail_where="comm_init"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     FakeCommBackend.fail_on_rank = fail_on_rank
+    FakeCommBackend.fail_where = fail_where
     accum = torch.zeros((W, H, 3), dtype=torch.float32)
     be = FakeCommBackend(accum)
     dr = DistributedRenderer(be, accum)
@@ -113,6 +123,10 @@ def _comm_worker(rank, world, port, out_dir, fail_on_rank):
     assert ok == (fail_on_rank is None)                      # all ranks or none
     if ok:
         assert be.comm == (world, rank, bytes(range(128)))   # rank 0's id reached every rank
+    if fail_where != "comm_init":
+        # a failure that is known BEFORE the communicator is made keeps every rank out of comm_init (inside RCCL it
+        # is a collective: a rank entering it alone would wait for the others for ever)
+        assert not FakeCommBackend.entered_init and dr.library_merge_error
     merged = dr.render(W, H, TOTAL, 8, 1234)
     assert getattr(be, "merged_by_library", False) == ok
     np.save(os.path.join(out_dir, f"r{rank}.npy"), merged.numpy())
@@ -126,6 +140,17 @@ def test_library_merge_handshake(tmp_path, fail_on_rank):
     the library merges (a rank that cannot set RCCL up sends everyone to the torch.distributed path),
     and the merged sums are the same either way."""
     mp.spawn(_comm_worker, args=(2, _free_port(), str(tmp_path), fail_on_rank), nprocs=2, join=True)
+    want = _value(range(0, TOTAL))
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), want)
+
+
+@pytest.mark.parametrize("fail_on_rank,fail_where", [(0, "unique_id"), (1, "ready"), (0, "ready")])
+def test_library_merge_handshake_failures_before_the_communicator(tmp_path, fail_on_rank, fail_where):
+    """Rank 0 cannot make the communicator id (librccl.so does not open there), or some rank cannot open the
+    library: the ranks still make the same collectives - rank 0 broadcasts None, readiness is gathered before
+    anyone enters comm_init - so nobody hangs, all fall back to torch.distributed, and the sums are right."""
+    mp.spawn(_comm_worker, args=(2, _free_port(), str(tmp_path), fail_on_rank, fail_where), nprocs=2, join=True)
     want = _value(range(0, TOTAL))
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), want)

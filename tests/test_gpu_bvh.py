@@ -198,6 +198,44 @@ def test_render_large_mesh_against_oracle_paths(backend):
     assert bad <= 2, f"{bad} of {len(xys)} paths differ"
 
 
+def test_render_rectangle_of_large_mesh_against_oracle(backend):
+    """rt_render ITSELF at 1.18 M triangles - the lean kernel with its sliced, resumable walk, the top levels of
+    the hierarchy in LDS, the held leaves, the set-aside paths and the launch that finishes them - against the
+    oracle's brute-force render of the same rectangle (origin rule, same sample sequence).  The rectangle is
+    put on the mesh's silhouette, where paths graze the dense mesh.  Pixels agree to float32 rounding; at most
+    two may differ (a path that runs along an edge of the room can pick the other face with float32 origins)."""
+    base = h.packed_scene("room_horse")
+    sc = base.with_subdivided_mesh(base.n_meshes - 1, 6)
+    backend.set_scene(sc)
+    assert backend.scene_layout()["bvh_nodes"] > 500_000
+    W, H, b, spp, rw, rh = 96, 54, 8, 4, 24, 14
+    # where the camera sees the mesh: the window with mesh and room pixels in equal parts
+    xys = np.array([(x, y, 0) for x in range(W) for y in range(H)], np.int32)
+    first = backend.trace_paths(xys, W, H, 0, h.SEED_RENDER)["obj"][:, 0].reshape(W, H)
+    on_mesh = (first == int(sc.mesh_obj[-1])).astype(np.int64)
+    csum = np.pad(on_mesh.cumsum(0).cumsum(1), ((1, 0), (1, 0)))
+    cnt = csum[rw:, rh:] - csum[:-rw, rh:] - csum[rw:, :-rh] + csum[:-rw, :-rh]
+    x0, y0 = np.unravel_index(np.argmin(np.abs(cnt - rw * rh // 2)), cnt.shape)
+    rect = (int(x0), int(x0) + rw, int(y0), int(y0) + rh)
+    assert 0.2 * rw * rh < cnt[x0, y0] < 0.8 * rw * rh, f"no window on the mesh's silhouette: best holds {cnt[x0, y0]} mesh pixels"
+    backend.resize(W, H)
+    backend.reset_stats()
+    backend.render(W, H, 0, spp, b, h.SEED_RENDER, rect=rect)
+    backend.synchronize()
+    img = backend.read().astype(np.float64)
+    st, cnts = backend.stats(), backend.render_counters()
+    with h.origin_rule():
+        ref, rays = h.oracle_render(sc, W, H, spp, b, rect=rect)
+    inside = np.zeros((W, H), bool)
+    inside[rect[0]:rect[1], rect[2]:rect[3]] = True
+    assert not img[~inside].any() and np.isfinite(img).all()
+    off = (np.abs(img - ref).max(axis=2) > 1e-3 * (1.0 + ref.max(axis=2))) & inside
+    print(f"\nrectangle {rect}: {int(off.sum())} of {rw * rh} pixels differ; rays {st['rays']} (oracle {rays}), "
+          f"boxes per ray {st['bvh_node_tests'] / st['rays']:.1f}, set aside {cnts['paths_set_aside']} paths")
+    assert abs(st["rays"] - rays) <= 16 and st["bvh_node_tests"] > 0
+    assert off.sum() <= 2, f"{int(off.sum())} pixels differ from the oracle"
+
+
 def test_bad_hierarchy_is_rejected(backend):
     from raytracing_amd.backend.bvh import build_flat_bvh
     from raytracing_amd.backend.lib import BackendError

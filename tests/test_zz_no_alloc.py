@@ -33,8 +33,22 @@ def test_noalloc_postprocess_equals_the_allocating_entry_twice_in_a_row():
     g = torch.Generator(device="cpu").manual_seed(11)
     big = (torch.rand((1920, 1080, 3), generator=g) * 3.0).to("cuda:0")        # 8100 blocks wanted -> every slot in use
     small = (torch.rand((37, 23, 3), generator=g) * 0.7).to("cuda:0")          # 4 blocks: almost all slots stale
+    # "allocates nothing": with every buffer the calls touch allocated beforehand, the device's free memory must not
+    # move across three calls of the entry point (a hipMalloc inside it would show here; torch's own caching allocator
+    # is kept out of the span: the destination tensors exist before it and nothing is copied to the host inside it)
+    stream = torch.cuda.current_stream().cuda_stream
+    dst_big = torch.full((1920, 1080, 3), -1.0, dtype=torch.float32, device="cuda:0")
+    dst_small = torch.full((37, 23, 3), -1.0, dtype=torch.float32, device="cuda:0")
+    kw = dict(scale=0.5, flip_y=True, exposure=2.0, brightness=0.02, contrast=1.1, saturation=1.2, gamma=0.8, stream=stream, no_alloc=True)
+    be.postprocess(37, 23, dst_small.data_ptr(), src_ptr=small.data_ptr(), **kw)   # (the runtime loads a kernel's code on its first launch)
+    torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info(0)[0]
+    for src, dst in ((big, dst_big), (small, dst_small), (big, dst_big)):
+        be.postprocess(src.shape[0], src.shape[1], dst.data_ptr(), src_ptr=src.data_ptr(), **kw)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] == free0, "rt_postprocess_noalloc changed the device's free memory"
     got_big = _run(be, torch, big, True)
+    assert np.array_equal(dst_big.cpu().numpy(), got_big)
     got_small = _run(be, torch, small, True)
     want_big = _run(be, torch, big, False)
     want_small = _run(be, torch, small, False)
@@ -47,7 +61,6 @@ def test_noalloc_postprocess_equals_the_allocating_entry_twice_in_a_row():
     assert np.abs(got_small - ref).max() <= 2e-5
     # a third call after the allocating entry has run in between, same answer again
     assert np.array_equal(_run(be, torch, small, True), want_small)
-    del free0
     # beyond the stated maximum: refused, nothing launched
     with pytest.raises(BackendError) as ei:
         be.postprocess(16384, 8192, 1, src_ptr=1, no_alloc=True)
