@@ -100,7 +100,8 @@ enum {
     RT_SCENE_NO_PAIR_ROWS = 1,     /* every triangle a table row of its own (no parallelogram rows) */
     RT_SCENE_NO_COMPACT_ROWS = 2,  /* no compact rows for parallelograms in axis-perpendicular planes */
     RT_SCENE_NO_LINEAR_SPLIT = 4,  /* hierarchy scenes: scene-sized triangles go into the hierarchy too */
-    RT_SCENE_NO_LDS_TOP = 8,       /* hierarchy scenes: top levels read from memory instead of LDS */
+    RT_SCENE_TINY_WALK_STACK = 8,  /* hierarchy scenes: a walk may stack six nodes instead of 24, so that most walks fall back to
+                                    * the stackless walk of last resort (tests of that walk) */
     RT_SCENE_NO_BOX_ROWS = 16,     /* no box rows (axis-aligned boxes whose faces are tested with one slab test) */
     /* Moved meshes (upstream: Mesh.update_transformed_vertices, src/mesh/mesh.py:178-209, which rebuilds
      * nothing because it has no acceleration structure): when the context's current hierarchy was built

@@ -68,7 +68,7 @@ class RtSceneDesc(C.Structure):
 
 
 # rt_scene_desc.flags
-RT_SCENE_NO_PAIR_ROWS, RT_SCENE_NO_COMPACT_ROWS, RT_SCENE_NO_LINEAR_SPLIT, RT_SCENE_NO_LDS_TOP, RT_SCENE_NO_BOX_ROWS, RT_SCENE_REFIT = 1, 2, 4, 8, 16, 32
+RT_SCENE_NO_PAIR_ROWS, RT_SCENE_NO_COMPACT_ROWS, RT_SCENE_NO_LINEAR_SPLIT, RT_SCENE_TINY_WALK_STACK, RT_SCENE_NO_BOX_ROWS, RT_SCENE_REFIT = 1, 2, 4, 8, 16, 32
 
 
 def layout_switches() -> dict:
@@ -82,8 +82,8 @@ def layout_switches() -> dict:
         flags |= RT_SCENE_NO_COMPACT_ROWS
     if env.get("RAYTRACING_AMD_NO_LINEAR_SPLIT"):
         flags |= RT_SCENE_NO_LINEAR_SPLIT
-    if env.get("RAYTRACING_AMD_NO_LDS_TOP"):
-        flags |= RT_SCENE_NO_LDS_TOP
+    if env.get("RAYTRACING_AMD_TINY_WALK_STACK"):
+        flags |= RT_SCENE_TINY_WALK_STACK
     if env.get("RAYTRACING_AMD_NO_BOXES"):
         flags |= RT_SCENE_NO_BOX_ROWS
 

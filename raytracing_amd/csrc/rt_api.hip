@@ -98,7 +98,8 @@ struct rt_ctx {
     int tri_mode = 0; bool has_sph = false;
     DevBuf tri_rows, quad_rows, slab_rows, box_rows, box_face_id, box_face_rows, leaf_rows, sph_rows, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
     DevBuf tri_tight;
-    DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_tri, cold;
+    DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_wide, bvh_tri, cold;
+    int32_t walk_stack_need = 0;   // stack entries the deepest walk of the current wide hierarchy can ask for
     DevBuf accum; int acc_w = 0, acc_h = 0;
     DevBuf partial, job_counter, stats;
     DevBuf aside, aside_head, dirty, dirty_list;   // rt_render: paths set aside by the lean kernel, jobs it gave up (grow-only)
@@ -834,35 +835,16 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
     HIP_TRY(c, c->mesh_tri_begin.upload(mtb)); HIP_TRY(c, c->obj_kind.upload(okind)); HIP_TRY(c, c->obj_index.upload(oindex));
     if (has_sky) HIP_TRY(c, c->sky.upload(sky));
-    int32_t n_top_nodes = 0;
     if (use_bvh) {
-        // Device form: eight threadings of the one hierarchy, one per octant of ray directions (children
-        // nearer along the ray first), each laid out top levels first - the kernels stage those in LDS -
-        // and depth-first below.
-        std::vector<rt_bvh_node> all(8 * bvh_nodes.size());
-        int32_t tops[8] = {0};
-        auto thread_octant = [&](int oct) {   // the eight threadings are independent of each other
-            std::vector<rt_bvh_node> one, dev;
-            bvh::rethread(bvh_nodes, oct, one);
-            tops[oct] = bvh::reorder_top_first(one, kTopNodes, dev);
-            // what the walk reads per node: the planes this octant's rays enter through in `lo`, those they leave
-            // through in `hi`; an inner node's first child always spelled out (-(child + 2))
-            for (size_t i = 0; i < dev.size(); ++i) {
-                for (int k = 0; k < 3; ++k) if ((oct >> k) & 1) std::swap(dev[i].lo[k], dev[i].hi[k]);
-                if (dev[i].tri_begin_count == -1) dev[i].tri_begin_count = -((int32_t)i + 1 + 2);
-            }
-            std::copy(dev.begin(), dev.end(), all.begin() + (size_t)oct * bvh_nodes.size());
-        };
-        if (bvh_nodes.size() >= 65536) {
-            std::vector<std::thread> pool;
-            for (int oct = 1; oct < 8; ++oct) pool.emplace_back(thread_octant, oct);
-            thread_octant(0);
-            for (auto &t : pool) t.join();
-        } else {
-            for (int oct = 0; oct < 8; ++oct) thread_octant(oct);
-        }
-        n_top_nodes = tops[0];   // level sizes, hence the count, are the same for every octant
-        HIP_TRY(c, c->bvh.upload(all));
+        // Device form: the wide hierarchy the kernels walk (four children per node, one copy for every ray
+        // direction), and the threaded two-child hierarchy as the builder left it, for the walk of last resort.
+        std::vector<WideNode> wide;
+        int32_t need = 0;
+        if (!bvh::collapse_wide(bvh_nodes, wide, &need))
+            return fail(c, RT_ERR_UNSUPPORTED, "hierarchy of %zu nodes: the wide form holds at most 2^24 nodes (use larger leaves)", bvh_nodes.size());
+        c->walk_stack_need = need;
+        HIP_TRY(c, c->bvh.upload(bvh_nodes));
+        HIP_TRY(c, c->bvh_wide.upload(wide));
     }
 
     DevScene &S = c->S;
@@ -880,7 +862,8 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.tri_tight = c->tri_tight.as<float>();
     S.leaf_rows = c->leaf_rows.as<TriRow>();
     S.bvh_nodes = use_bvh ? c->bvh.as<BvhNode>() : nullptr; S.n_bvh_nodes = use_bvh ? (int32_t)bvh_nodes.size() : 0;
-    S.n_top_nodes = (d->flags & RT_SCENE_NO_LDS_TOP) ? 0 : n_top_nodes;   // switch for A/B runs
+    S.wide_nodes = use_bvh ? c->bvh_wide.as<WideNode>() : nullptr;
+    S.walk_stack = (d->flags & RT_SCENE_TINY_WALK_STACK) ? 6 : kWalkStack;   // (the flag: tests of the walk of last resort)
     ColdScene cold{};
     cold.tri64 = c->tri64.as<double>(); cold.sph64 = c->sph64.as<double>(); cold.aabb64 = c->aabb64.as<double>();
     cold.mesh_tri_begin = c->mesh_tri_begin.as<int32_t>(); cold.obj_kind = c->obj_kind.as<int32_t>(); cold.obj_index = c->obj_index.as<int32_t>();

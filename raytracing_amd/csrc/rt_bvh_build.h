@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/raytracing_amd.h"
+#include "rt_scene.h"
 
 namespace rt {
 namespace bvh {
@@ -377,6 +378,94 @@ inline int32_t reorder_top_first(const std::vector<rt_bvh_node> &src, int32_t ma
         dst[where[i]] = nd;
     }
     return n_top;
+}
+
+// The wide form of a valid threaded hierarchy (see WideNode): every node takes its two children and then, while it
+// has fewer than four, replaces the inner child with the largest box by that child's two children.  A node's inner
+// children get consecutive indices (in slot order), and the nodes are laid out depth first by such blocks, so a walk
+// down the first children reads ascending addresses.  Leaves keep their triangle ranges.  For each octant of ray
+// directions the slots are ordered by the projection of the box centres on that octant's diagonal.
+// `stack_need` receives the largest number of stack entries any walk can ask for (a visit pushes every inner child
+// that is hit and pops one: the sum of (inner children - 1) along a root-to-node path, plus that node's own).
+// Returns false when the hierarchy has more nodes than the walk's 24-bit node numbers can name.
+inline bool collapse_wide(const std::vector<rt_bvh_node> &src, std::vector<WideNode> &out, int32_t *stack_need) {
+    const int32_t n = (int32_t)src.size();
+    out.clear();
+    if (stack_need) *stack_need = 0;
+    if (n == 0) return true;
+    auto end_of = [&](int32_t i) { return src[i].skip < 0 ? n : src[i].skip; };
+    auto is_leaf = [&](int32_t i) { return src[i].tri_begin_count >= 0; };
+    auto area = [&](int32_t i) {
+        const double dx = (double)src[i].hi[0] - src[i].lo[0], dy = (double)src[i].hi[1] - src[i].lo[1], dz = (double)src[i].hi[2] - src[i].lo[2];
+        return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.0;
+    };
+    auto up32 = [](double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; };
+    struct Work { int32_t src, wide, pending; };   // pending: stack entries in use when the walk reaches this node
+    std::vector<Work> todo;
+    out.push_back(WideNode{});
+    todo.push_back({0, 0, 0});
+    int32_t need = 0;
+    while (!todo.empty()) {
+        const Work w = todo.back(); todo.pop_back();
+        int32_t kids[4]; int nk = 0;
+        if (is_leaf(w.src)) kids[nk++] = w.src;     // (a hierarchy that is one leaf: the root holds it)
+        else {
+            kids[nk++] = w.src + 1; kids[nk++] = end_of(w.src + 1);
+            while (nk < 4) {
+                int best = -1; double best_area = -1.0;
+                for (int k = 0; k < nk; ++k) if (!is_leaf(kids[k]) && area(kids[k]) > best_area) { best_area = area(kids[k]); best = k; }
+                if (best < 0) break;
+                const int32_t c = kids[best], l = c + 1, r = end_of(l);
+                for (int k = nk; k > best + 1; --k) kids[k] = kids[k - 1];
+                kids[best] = l; kids[best + 1] = r; ++nk;
+            }
+        }
+        WideNode nd{};
+        double centre[4][3] = {{0}};
+        uint32_t inner = 0, used = 0;
+        for (int k = 0; k < 4; ++k) {
+            float c[3] = {0, 0, 0}, h[3] = {-1e30f, -1e30f, -1e30f};
+            if (k < nk) {
+                const rt_bvh_node &b = src[kids[k]];
+                for (int a = 0; a < 3; ++a) {
+                    const double mid = 0.5 * ((double)b.lo[a] + (double)b.hi[a]);
+                    c[a] = std::isfinite(mid) ? (float)mid : 0.0f;
+                    // the half-extent covers the rounding of the centre: [c - h, c + h] contains [lo, hi] (empty box: stays empty)
+                    const double hh = std::max((double)b.hi[a] - (double)c[a], (double)c[a] - (double)b.lo[a]);
+                    h[a] = hh >= 0 ? std::min(up32(hh * (1.0 + 1e-7)), 3.0e38f) : -1e30f;
+                    centre[k][a] = c[a];
+                }
+                used |= 1u << k;
+                if (is_leaf(kids[k])) nd.link[k] = b.tri_begin_count; else { inner |= 1u << k; nd.link[k] = -1; }
+            } else nd.link[k] = 0;   // (an empty slot is never hit; a zero-count leaf if it ever were)
+            nd.cx[k] = c[0]; nd.hx[k] = h[0]; nd.cy[k] = c[1]; nd.hy[k] = h[1]; nd.cz[k] = c[2]; nd.hz[k] = h[2];
+        }
+        for (int oct = 0; oct < 8; ++oct) {
+            int idx[4] = {0, 1, 2, 3};
+            double key[4];
+            for (int k = 0; k < 4; ++k) {
+                key[k] = k < nk ? 0.0 : INFINITY;   // empty slots last
+                for (int a = 0; a < 3 && k < nk; ++a) key[k] += ((oct >> a) & 1) ? -centre[k][a] : centre[k][a];
+            }
+            std::stable_sort(idx, idx + 4, [&](int x, int y) { return key[x] < key[y]; });
+            uint32_t byte = 0;
+            for (int j = 0; j < 4; ++j) byte |= (uint32_t)idx[j] << (2 * j);
+            nd.order[oct >> 2] |= byte << (8 * (oct & 3));
+        }
+        const int n_inner = __builtin_popcount(inner);
+        nd.first = (int32_t)out.size();
+        nd.inner = inner | (used << 4);
+        need = std::max(need, w.pending + n_inner);
+        for (int k = 0; k < n_inner; ++k) out.push_back(WideNode{});
+        out[w.wide] = nd;
+        // children are worked on in slot order (the work list is a stack: push them in reverse)
+        int rank = n_inner;
+        for (int k = 3; k >= 0; --k)
+            if (inner & (1u << k)) { --rank; todo.push_back({kids[k], nd.first + rank, w.pending + n_inner - 1}); }
+        if (out.size() >= (size_t)(1 << 24)) return false;
+    }
+    if (stack_need) *stack_need = need;
+    return true;
 }
 
 // Structural and containment checks.  Returns an empty string when the hierarchy is safe to use:

@@ -701,135 +701,194 @@ RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
     }
 }
 
-// Stackless walk of the threaded hierarchy (node layout: rt_bvh_node).  Conservative slab test: the
-// computed entry/exit parameters carry a relative error of at most 5 u, which moves a box plane by
-// at most 5 u |plane - o| <= 5 u (S + |o|) (S = scene radius); rounding the ray origin, the stored
-// planes and o +- pad adds less than 3 u (S + |o|).  So every box is widened per ray by
-// pad = 10 u (S + |o|) - folded into the origin, at no cost per node - and plain comparisons can
-// then never drop a box the exact ray touches.  (The same bound holds for the multiply-add form used
-// below, plane * (1 / d) - (o +- pad) * (1 / d): the reciprocal's error is common to both terms and the
-// two roundings of the second term move the origin by less than 2 u |o|.)  A direction component of
-// zero makes both terms infinite: the value is the right infinity when they agree in sign and NaN when
-// they do not - that slab is then unconstrained, which only costs visits.  A NaN slab value (0 x inf: origin exactly on a box plane, direction component zero) drops out of
-// min/max and leaves that slab unconstrained.  A box is skipped when the ray misses it or enters it
-// beyond the sink's bound.
-typedef const f4 __attribute__((address_space(3))) *lds_f4_ptr;
-#ifndef RT_WALK_FLAT
-#define RT_WALK_FLAT 1   // 1: one load through a generic pointer (LDS or memory) per node; 2: memory only (measured equal:
-                         // 44.3 against 44.5 ms at 1.18 M triangles, 32 samples per pixel; a branch with a load on either side: +1.6 ms)
-#endif
-
-// Per-query walk context: test counters, and where the top levels of the hierarchy sit in LDS (if the
-// kernel staged them: n_top = 0 reads every node from memory).
-struct BvhCounters {
-    uint32_t nodes, tris;
-    lds_f4_ptr top; int32_t n_top;
-};
-
-RT_DEV BvhCounters bvh_counters() { BvhCounters b; b.nodes = 0; b.tris = 0; b.top = nullptr; b.n_top = 0; return b; }
-
+// ---------------------------------------------------------------------------------------------
+// Hierarchy walk (scenes beyond a few dozen triangles).  Upstream has none: Mesh.intersect loops over every
+// face (mesh.py:94-107); the walk only decides WHICH triangles are tested and must never hide one.
 //
-// The walk is resumable: it starts at `node` (0 = root), visits at most `budget` boxes before
-// returning, and leaves in `node` where to go on (-1 = finished).  The render kernel walks in
-// slices so that lanes whose rays finish early can take new work instead of idling until the
-// slowest ray of the wave (one that grazes a dense mesh visits ten times the average) is through.
-template <class Sink>
-RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, int &node, int budget) {
+// The kernels walk the WIDE hierarchy (WideNode: four children per node, every child's box in the node): one visit
+// loads one 128-byte node and answers four box tests, so a ray that needs 37 boxes of a two-child hierarchy waits
+// for about a dozen dependent loads instead of 37.  Children that are hit go on a per-lane stack in LDS (inner
+// children, nearest on top - the order comes from a per-octant table in the node) or into the lane's list of
+// pending leaves, whose triangles all lanes of the wave test together at the end of a sub-slice.
+//
+// Conservative slab test.  A child's box is centre c and half-extent h per axis ([c - h, c + h] contains the true
+// box).  With i = 1 / d (1 ulp = 2 u, u = 2^-24) the ray is inside the slab for tc - th <= t <= tc + th,
+//     tc = c i + k,  k = -(o i),  th = h |i| + pad |i|:
+// k carries u |o i|, the multiply-add of tc u |tc|, th u |th|, the sum or difference u of itself, and the reciprocal
+// rescales everything by at most 2 u.  Divided by |i| - in units of length along the axis - that is at most
+// u (|o| + |c - o| + h + pad + |c| + h + |o|) + 2 u (|c - o| + h) < 9 u (S + |o|) with S the scene radius (|c| + h <= S).
+// So every box is widened per ray by pad = 10 u (S + |o|), which costs one multiply-add per axis and ray, and plain
+// comparisons then never drop a box the exact ray touches.  The same holds for any finite i: only the second pass ever
+// walks a ray with a zero direction component (ray_route keeps such rays away from the first pass); there the
+// reciprocals are capped at 1e18, so a zero component gives tc = (c - o) 1e18 - far outside every other axis' values
+// when the origin is outside the slab (entry beyond exit, or exit behind the origin: a miss, as upstream's 1e10
+// pseudo-inverse gives, mesh.py:70-74) and an entry far behind, an exit far ahead when it is inside.  The test is
+// symmetric in the sign of i, so -0.0 needs no care.  A box is skipped when the ray misses it or enters it beyond the
+// sink's bound (the upper depth bound of a triangle that is certainly hit).
+//
+// Stack.  kWalkStack entries per lane; the builder reports what the deepest walk can need (collapse_wide) and the
+// scenes of the tests and benchmarks stay below it.  A lane whose stack would run full all the same (a caller's
+// hierarchy may be any shape) gives the wide walk up and walks the threaded two-child hierarchy from the root
+// instead - no stack, every triangle the ray could hit is met again; candidates the sinks have seen already do no
+// harm (a first pass that sees a candidate twice finds a runner-up at the winner's depth and settles the query in
+// double precision).
+// ---------------------------------------------------------------------------------------------
+__shared__ uint32_t g_walk_lds[4 * (kWalkStack + kWalkPending) * 64];   // [wave of the workgroup][entry][lane]; 32 KB
+
+// Per-query walk context: test counters.
+struct BvhCounters { uint32_t nodes, tris; };
+
+RT_DEV BvhCounters bvh_counters() { BvhCounters b; b.nodes = 0; b.tris = 0; return b; }
+
+// What the walk needs of a ray, worked out once per call.
+struct WalkRay { float ix, iy, iz, ax, ay, az, kx, ky, kz, px, py, pz; };
+
+template <bool CAPPED>
+RT_DEV WalkRay walk_ray(SceneRef S, const Ray &r) {
+    WalkRay w;
     const float pad = 10.0f * kU * (r.o2 + S.scene_radius);
-    // the threading for this ray's octant: children nearer along the ray come first, and every node of
-    // that copy holds the planes the ray ENTERS through in its first half, the planes it leaves through
-    // in its second - no min / max per axis
-    const bool bx = r.dx < 0.0f, by = r.dy < 0.0f, bz = r.dz < 0.0f;   // (-0.0 counts as "not negative")
-    float ix = rcp_(r.dx), iy = rcp_(r.dy), iz = rcp_(r.dz);
-    // Only the second pass ever walks a ray with a zero direction component (ray_route keeps such rays away from
-    // the first pass).  There the reciprocals are capped at 1e18 and take their sign from the octant: a zero
-    // component then gives a slab value of +-(distance to the plane) x 1e18 - far beyond every other axis' values,
-    // with the sign that says on which side of the plane the origin lies - where an infinite reciprocal gives
-    // NaN ("unconstrained") for half the planes and such a ray would visit every box along its other two
-    // axes (measured: 35 such rays per 32 samples per pixel added 2.5 ms to the path launch at 1.18 M
-    // triangles); and -0.0, whose reciprocal is -inf, goes with the plane order of the octant it is filed under
-    // (taken as it is, such a ray entered every box at +inf and missed the whole mesh).  The error bound above
-    // holds for any finite reciprocal - every term scales with it - so a box the ray touches is never dropped.
-    if (Sink::kPerTriangle) {
+    w.ix = rcp_(r.dx); w.iy = rcp_(r.dy); w.iz = rcp_(r.dz);
+    if (CAPPED) {   // (second passes only: see above)
         const float cap = 1e18f;
-        ix = bx ? -min_(abs_(ix), cap) : min_(abs_(ix), cap);
-        iy = by ? -min_(abs_(iy), cap) : min_(abs_(iy), cap);
-        iz = bz ? -min_(abs_(iz), cap) : min_(abs_(iz), cap);
+        w.ix = u2f((f2u(w.ix) & 0x80000000u) | f2u(min_(abs_(w.ix), cap)));
+        w.iy = u2f((f2u(w.iy) & 0x80000000u) | f2u(min_(abs_(w.iy), cap)));
+        w.iz = u2f((f2u(w.iz) & 0x80000000u) | f2u(min_(abs_(w.iz), cap)));
     }
-    const int oct = (bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0);
-    // entry = plane * (1 / d) + k, one multiply-add per plane; the widening sits in k: the entry value is
-    // computed from an origin moved forward along the axis by `pad`, the exit value from one moved back
-    const float sx = bx ? -pad : pad, sy = by ? -pad : pad, sz = bz ? -pad : pad;
-    const float knx = -(r.ox + sx) * ix, kny = -(r.oy + sy) * iy, knz = -(r.oz + sz) * iz;
-    const float kfx = -(r.ox - sx) * ix, kfy = -(r.oy - sy) * iy, kfz = -(r.oz - sz) * iz;
-    const f4 *nodes = (const f4 *)(S.bvh_nodes + (size_t)oct * (size_t)S.n_bvh_nodes);
-    const lds_f4_ptr top = bc.top + 2 * kTopNodes * oct;
+    w.ax = abs_(w.ix); w.ay = abs_(w.iy); w.az = abs_(w.iz);
+    w.kx = -(r.ox * w.ix); w.ky = -(r.oy * w.iy); w.kz = -(r.oz * w.iz);
+    w.px = pad * w.ax; w.py = pad * w.ay; w.pz = pad * w.az;
+    return w;
+}
+
+template <class Sink>
+RT_DEV void test_leaf_row(const TriRow *rows, int row, const Ray &r, Sink &sink) {
+    const TriRow cur = load_tri_row_lane(rows, row);
+    float sure_thi;
+    const float tl = tri_tlo<true>(cur, r, &sure_thi);
+    sink.certain_hit(sure_thi);
+    sink(tl, cur.gprim);
+}
+
+// The walk of last resort: the threaded two-child hierarchy from the root to the end, no stack (box hit -> the next
+// node, or the leaf's triangles and on to `skip`; miss -> `skip`).  Planes as stored, minimum / maximum per axis.
+template <class Sink>
+RT_DEV void walk_threaded(SceneRef S, const Ray &r, const WalkRay &w, Sink &sink, BvhCounters &bc) {
+    const f4 *nodes = (const f4 *)S.bvh_nodes;
     const TriRow *rows = S.leaf_rows;
-    if (S.n_bvh_nodes <= 0) node = -1;
+    int node = S.n_bvh_nodes > 0 ? 0 : -1;
+    while (node >= 0) {
+        const f4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
+        const int32_t skip = (int32_t)f2u(a.w), info = (int32_t)f2u(b.w);
+        const float x0 = fma_(a.x, w.ix, w.kx), x1 = fma_(b.x, w.ix, w.kx);
+        const float y0 = fma_(a.y, w.iy, w.ky), y1 = fma_(b.y, w.iy, w.ky);
+        const float z0 = fma_(a.z, w.iz, w.kz), z1 = fma_(b.z, w.iz, w.kz);
+        const float tn = max_(max3_(min_(x0, x1) - w.px, min_(y0, y1) - w.py, min_(z0, z1) - w.pz), 0.0f);
+        const float tf = min_(min3_(max_(x0, x1) + w.px, max_(y0, y1) + w.py, max_(z0, z1) + w.pz), sink.prune_bound());
+        const bool hit = tn <= tf;
+        bc.nodes += 1u;
+        if (hit && info >= 0) {
+            const int first = info >> 4, cnt = info & 15;
+            bc.tris += (uint32_t)cnt;
+            for (int k = 0; k < cnt; ++k) test_leaf_row(rows, first + k, r, sink);
+        }
+        node = (hit && info < 0) ? node + 1 : skip;
+    }
+}
+
+// The walk is resumable: `state` says where it stands (0 = at the root with an empty stack; otherwise the node to
+// visit next in bits 0-23 and the number of stack entries above it; -1 = finished), it visits at most `budget` nodes
+// before returning and leaves in `state` where to go on.  The render kernel walks in slices so that lanes whose rays
+// finish early can take new work instead of idling until the slowest ray of the wave (one that grazes a dense mesh
+// visits ten times the average) is through.  The lane's stack lives in its column of g_walk_lds from one call to the
+// next; nothing else may walk on this lane in between.
+constexpr int kSubSlice = 3;   // nodes a lane visits between two rounds of triangle tests
+
+template <class Sink>
+RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, int &state, int budget) {
+    const WalkRay w = walk_ray<Sink::kPerTriangle>(S, r);
+    const int oct = (r.dx < 0.0f ? 1 : 0) | (r.dy < 0.0f ? 2 : 0) | (r.dz < 0.0f ? 4 : 0);
+    const uint32_t order_shift = 8u * (uint32_t)(oct & 3);
+    const bool order_hi = oct >= 4;
+    const f4 *nodes = (const f4 *)S.wide_nodes;
+    const TriRow *rows = S.leaf_rows;
+    // this lane's column: stack entries 0 .. kWalkStack - 1, then the pending leaves
+    uint32_t *const col = g_walk_lds + ((threadIdx.x >> 6) * (kWalkStack + kWalkPending)) * 64 + (threadIdx.x & 63);
+    uint32_t *const pend_col = col + kWalkStack * 64;
+    const int cap = S.walk_stack;
+    int cur = S.n_bvh_nodes > 0 ? (state < 0 ? -1 : (state & 0xFFFFFF)) : -1;
+    int sp = state < 0 ? 0 : (state >> 24);
     int visited = 0;
-    // Each trip of the outer loop is a sub-slice: every lane walks boxes until it holds three leaves
-    // (after the first it goes on - the leaves wait) or has used the sub-slice up; then all lanes that
-    // hold leaves test their triangles TOGETHER.  Testing a leaf the moment a lane finds it would run
-    // the triangle code for that one lane while the others wait ("while-while" loops still did that
-    // three or four times per slice).
-    // Measured at 1.18 M triangles, G rays/s, with the loop body as nested ifs: one pending leaf, sub-slices
-    // of 2 / 4 / 8 boxes: 4.58 / 4.84 / 4.72; two pending leaves (stopping before a third), sub-slices of
-    // 4 / 6 / 8: 5.32 / 5.37 / 5.43.  With the branch-free body, kernel time for 32 samples per pixel: two
-    // pending leaves, stopping before a third 46.2 ms; stopping once two are held 48.6; three held 44.3.
-    constexpr int kSubSlice = 8;
-    while (visited < budget && node >= 0) {
+    bool overflow = false;
+    while (visited < budget && cur >= 0) {
         const int stop = visited + kSubSlice < budget ? visited + kSubSlice : budget;
-        const int visited0 = visited;
-        int32_t leaf = -1, leaf2 = -1, leaf3 = -1;
-        // The body is written without branches (selects only): as nested ifs it compiled to some forty
-        // scalar mask and branch instructions per box, more than the box test itself.  Leaves are held
-        // newest first.
-        while (node >= 0 && visited < stop && leaf3 < 0) {
+        int pend = 0;
+        // The body is written without branches (selects, and stores whose address moves on only when they count):
+        // as nested ifs such a body compiles to more scalar mask and branch instructions than the box tests take.
+        while (cur >= 0 && visited < stop && pend <= kWalkPending - 4 && sp + 4 <= cap) {
             PROF_LANES(kProfWalkIters, (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))); PROF_LANES(kProfWalkLanes, true);
-#if RT_WALK_FLAT == 2
-            const f4 *q = nodes + 2 * (size_t)node;
-#else
-            // top levels from LDS, the rest from memory, through ONE load: the pointer says which
-            const f4 *q = node < bc.n_top ? (const f4 *)(top + 2 * node) : nodes + 2 * (size_t)node;
-#endif
-            const f4 a = q[0], b = q[1];
-            const int32_t skip = (int32_t)f2u(a.w), info = (int32_t)f2u(b.w);
-            const float x0 = fma_(a.x, ix, knx), y0 = fma_(a.y, iy, kny), z0 = fma_(a.z, iz, knz);
-            const float x1 = fma_(b.x, ix, kfx), y1 = fma_(b.y, iy, kfy), z1 = fma_(b.z, iz, kfz);
-            const float tn = max_(max_(x0, y0), max_(z0, 0.0f));
-            const float tf = min_(min_(x1, y1), min_(z1, sink.prune_bound()));
-            const bool hit = tn <= tf;
-            const bool take = hit && info >= 0;          // a leaf the ray may touch
-            leaf3 = take ? leaf2 : leaf3;
-            leaf2 = take ? leaf : leaf2;
-            leaf = take ? info : leaf;
-            node = (hit && info < 0) ? -2 - info : skip;   // inner node: its first child
+            const f4 *q = nodes + 8 * (size_t)cur;
+            const f4 cx = q[0], hx = q[1], cy = q[2], hy = q[3], cz = q[4], hz = q[5], lk = q[6], mt = q[7];
+            const float bound = sink.prune_bound();
+            uint32_t m = 0;
+#define RT_WIDE_CHILD(k, C)                                                                              \
+            {                                                                                            \
+                const float tcx = fma_(cx.C, w.ix, w.kx), thx = fma_(hx.C, w.ax, w.px);                  \
+                const float tcy = fma_(cy.C, w.iy, w.ky), thy = fma_(hy.C, w.ay, w.py);                  \
+                const float tcz = fma_(cz.C, w.iz, w.kz), thz = fma_(hz.C, w.az, w.pz);                  \
+                const float tn = max_(max3_(tcx - thx, tcy - thy, tcz - thz), 0.0f);                     \
+                const float tf = min_(min3_(tcx + thx, tcy + thy, tcz + thz), bound);                    \
+                m |= (tn <= tf) ? (1u << k) : 0u;                                                        \
+            }
+            RT_WIDE_CHILD(0, x) RT_WIDE_CHILD(1, y) RT_WIDE_CHILD(2, z) RT_WIDE_CHILD(3, w)
+#undef RT_WIDE_CHILD
+            const float o0 = mt.x, o1 = mt.y, fw = mt.z, iw = mt.w;   // (copies first: bit-casting a vector element expression reads lane 0)
+            const uint32_t inner = f2u(iw) & 15u, first = f2u(fw);
+            bc.nodes += (uint32_t)__builtin_popcount((f2u(iw) >> 4) & 15u);   // boxes tested: the slots that hold a child
+            const uint32_t order = ((order_hi ? f2u(o1) : f2u(o0)) >> order_shift) & 0xFFu;
+            const uint32_t mi = m & inner, ml = m & ~inner;
+            // leaves that are hit join the pending list, in slot order
+            {
+                const float l0 = lk.x, l1 = lk.y, l2 = lk.z, l3 = lk.w;
+                pend_col[64 * pend] = f2u(l0); pend += (int)(ml & 1u);
+                pend_col[64 * pend] = f2u(l1); pend += (int)((ml >> 1) & 1u);
+                pend_col[64 * pend] = f2u(l2); pend += (int)((ml >> 2) & 1u);
+                pend_col[64 * pend] = f2u(l3); pend += (int)((ml >> 3) & 1u);
+            }
+            // inner children that are hit go on the stack, farthest first
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                const uint32_t c = (order >> (2 * j)) & 3u;
+                const uint32_t child = first + (uint32_t)__builtin_popcount(inner & ((1u << c) - 1u));
+                col[64 * sp] = child; sp += (int)((mi >> c) & 1u);
+            }
+            // ... and the nearest comes off again
+            const bool more = sp > 0;
+            sp -= more ? 1 : 0;
+            const uint32_t top = col[64 * sp];
+            cur = more ? (int)top : -1;
             ++visited;
         }
-        bc.nodes += (uint32_t)(visited - visited0);
         PROF(kProfWalk);
-        if (leaf >= 0) {
-            // oldest first: candidates then reach the sink in the order the walk meets them, wherever its slices end
-            // (among candidates with equal lower bounds - 0 for everything that starts behind the origin - the sink
-            // keeps the first, so how a query gets settled, though not its result, depends on that order)
-            const int32_t la = leaf3 >= 0 ? leaf3 : (leaf2 >= 0 ? leaf2 : leaf);
-            const int32_t lb = leaf3 >= 0 ? leaf2 : (leaf2 >= 0 ? leaf : -1);
-            const int32_t lc = leaf3 >= 0 ? leaf : -1;
-            const int first = la >> 4, cnt0 = la & 15;
-            const int first2 = lb >= 0 ? lb >> 4 : 0, cnt1 = cnt0 + (lb >= 0 ? lb & 15 : 0);
-            const int first3 = lc >= 0 ? lc >> 4 : 0, cnt = cnt1 + (lc >= 0 ? lc & 15 : 0);
-            bc.tris += (uint32_t)cnt;
-            for (int k = 0; k < cnt; ++k) {
+        if (pend > 0) {
+            // the pending leaves' triangles, oldest leaf first: candidates reach the sink in the order the walk met them
+            int e = 0, k = 0;
+            uint32_t desc = pend_col[0];
+            while (e < pend) {
                 PROF_LANES(kProfLeafIters, (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))); PROF_LANES(kProfLeafLanes, true);
-                const TriRow cur = load_tri_row_lane(rows, k < cnt0 ? first + k : (k < cnt1 ? first2 + (k - cnt0) : first3 + (k - cnt1)));
-                float sure_thi;
-                const float tl = tri_tlo<true>(cur, r, &sure_thi);
-                sink.certain_hit(sure_thi);
-                sink(tl, cur.gprim);
+                const int cnt = (int)(desc & 15u);
+                test_leaf_row(rows, (int)(desc >> 4) + k, r, sink); bc.tris += 1u;
+                ++k;
+                const bool next = k >= cnt;
+                e += next ? 1 : 0; k = next ? 0 : k;
+                desc = pend_col[64 * (e < kWalkPending ? e : kWalkPending - 1)];
             }
         }
         PROF(kProfLeaves);
-        // a lane that stopped before a second leaf has budget left: it goes round again
+        if (cur >= 0 && sp + 4 > cap) { overflow = true; cur = -1; }
+    }
+    state = cur < 0 ? -1 : (cur | (sp << 24));
+    if (__ballot(overflow) != 0) {
+        if (overflow) walk_threaded(S, r, w, sink, bc);
     }
 }
 

@@ -300,7 +300,7 @@ RT_DEV KernargRenderArgs kernarg_render_args() {
 }
 
 constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at a time
-constexpr int kWalkSlice = 8;   // boxes a lane visits per trip of the render loop (hierarchy scenes)
+constexpr int kWalkSlice = 3;   // wide nodes (four boxes each) a lane visits per trip of the render loop (hierarchy scenes)
 
 // STRICT: a float32 hit depth is accepted only under the closest-hit entry's error bound (9.5e-6
 // relative) instead of the render's looser one (see kRelAcceptRender); hit identity is the same.
@@ -338,18 +338,7 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
     // is converged), not per lane: six vector registers less for the whole life of the kernel.
     uint32_t w_exact = 0, w_refine = 0;
     uint32_t l_rays = 0, l_sky = 0;   // this lane's own counts
-    // hierarchy scenes: the workgroup stages the top levels of the hierarchy in LDS once (every ray
-    // visits them; an LDS read costs a fraction of even an L1 hit and takes no vector-memory slot)
-    __shared__ f4 top_nodes[TRI == kTriBvh ? 8 * 2 * kTopNodes : 2];
     BvhCounters bc = bvh_counters();   // hierarchy only: per-lane test counts, reduced at the end
-    if (TRI == kTriBvh) {
-        for (int oct = 0; oct < 8; ++oct) {
-            const f4 *src = (const f4 *)(S.bvh_nodes + (size_t)oct * (size_t)S.n_bvh_nodes);
-            for (int i = threadIdx.x; i < 2 * S.n_top_nodes; i += 256) top_nodes[2 * kTopNodes * oct + i] = src[i];
-        }
-        __syncthreads();
-        bc.top = (lds_f4_ptr)top_nodes; bc.n_top = S.n_top_nodes;
-    }
     // hierarchy only: a closest-hit query in progress (walked a slice per trip of the main loop)
     typename FirstPass<TRI>::type first;
     first.init(S);

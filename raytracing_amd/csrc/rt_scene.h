@@ -13,7 +13,6 @@
 namespace rt {
 
 constexpr float kU = 5.9604644775390625e-08f;  // 2^-24, unit roundoff of binary32
-constexpr int kTopNodes = 128;                 // hierarchy nodes per ray octant a workgroup keeps in LDS (8 x 128 x 32 B = 32 KB)
 
 // One live triangle, 16 dwords = one s_load_dwordx16.
 // t = -(N.o + kN) / (N.d);  p = o + t d;  u = e1.p + k1;  v = e2.p + k2;  w = 1 - u - v
@@ -98,10 +97,32 @@ struct MatRow {      // 8 dwords per object
     float r, g, b, emission, smoothness, transmittance, ior, r0;  // r0 = ((1-ior)/(1+ior))^2
 };
 
-struct BvhNode {     // rt_bvh_node as the device holds it, per octant copy: `lo` = the planes rays of that octant enter
-    float lo[3]; int32_t skip;             // through, `hi` = the planes they leave through (swapped per axis where the
-    float hi[3]; int32_t tri_begin_count;  // octant's direction is negative); inner nodes: -(first child + 2), never -1
+struct BvhNode {     // rt_bvh_node as the device holds it (threaded depth-first order, one copy): the walk of last resort
+    float lo[3]; int32_t skip;             // reads it (a lane whose stack of wide nodes ran full); inner nodes:
+    float hi[3]; int32_t tri_begin_count;  // tri_begin_count < 0, first child = the next node
 };
+
+// One node of the WIDE hierarchy the kernels walk: up to four children, every child's box in the node itself, so
+// one visit (eight 16-byte loads from one 128-byte line) answers four box tests and a ray needs a third of the
+// dependent loads a two-child hierarchy costs it.  Boxes are stored as centre and half-extent per axis: with
+// tc = c / d - o / d and th = h / |d| the ray is inside the slab for tc - th <= t <= tc + th whatever the sign of d,
+// so one copy of the nodes serves every ray direction (no per-octant copies, no minimum / maximum per axis).
+// [c - h, c + h] contains the child's true box (the host rounds h up to cover the rounding of c).  An empty slot has
+// h = -1e30: its entry lies beyond its exit for every ray.
+//   link[k]   a LEAF child's triangle range (first row << 4 | count, rows of DevScene::leaf_rows); unused for inner children
+//   order[2]  for each octant of ray directions one byte (octant & 3 within word octant >> 2): four 2-bit slot
+//             numbers, the children from near to far for rays of that octant
+//   first     index of the node's first INNER child; its inner children are stored one after the other in slot order,
+//             so child k is node first + popcount(inner & ((1 << k) - 1)): no table of links to index per lane
+//   inner     bits 0-3: which slots hold inner nodes; bits 4-7: which slots hold anything
+struct WideNode {
+    float cx[4], hx[4], cy[4], hy[4], cz[4], hz[4];
+    int32_t link[4];
+    uint32_t order[2]; int32_t first; uint32_t inner;
+};
+static_assert(sizeof(WideNode) == 128, "WideNode: one 128-byte line");
+constexpr int kWalkStack = 24;     // entries of a lane's stack of wide nodes still to visit (LDS)
+constexpr int kWalkPending = 8;    // leaves a lane may hold before its triangles are tested (LDS, after the stack)
 
 // Scene data only the rare double-precision code, the depth-of-field camera and the ray-generation
 // kernel read.  It lives in device memory behind DevScene::cold, so that the render kernel does not
@@ -160,9 +181,9 @@ struct DevScene {
     // ---- the few huge spheres, the hierarchy
     const int32_t *big_sph;                           // sphere indices evaluated in float64
     const TriRow *leaf_rows;                          // hierarchy: triangle rows in leaf order
-    const BvhNode *bvh_nodes; int32_t n_bvh_nodes;    // threaded hierarchy over leaf_rows: 8 copies of n_bvh_nodes nodes, one per
-                                                      // ray-direction octant, each with its top levels first; 0 = none
-    int32_t n_top_nodes;                              // per copy, the first n_top_nodes nodes are the top levels (staged in LDS)
+    const BvhNode *bvh_nodes; int32_t n_bvh_nodes;    // threaded two-child hierarchy over leaf_rows (the walk of last resort); 0 = none
+    int32_t walk_stack;                               // stack entries a lane may use (kWalkStack; tests set it lower)
+    const WideNode *wide_nodes;                       // the same hierarchy with up to four children per node: what the kernels walk
     // Per plane, what the float32 row's rounding and the order of its multiply-adds can cost: four floats (ax, ay, az, ak)
     // per triangle (by triangle id), then per parallelogram row (by row index).  See judge_tri.
     const float *tri_tight;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_wf_generate(const DevScene S_arg, const
     if (p == 0) *A.count_in = A.n_paths;
 }
 
-constexpr int kWfSlice = 6;      // boxes per trip of the extend loop
+constexpr int kWfSlice = 3;      // wide nodes per trip of the extend loop
 constexpr int kWfGrab = 256;    // rays a wave reserves from the queue at a time (one atomic each: keep them rare,
                                  // same-address atomics complete at only ~0.1 G/s)
 
@@ -102,18 +102,7 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, cons
     typename FirstPass<TRI>::type first;
     first.init(S);
     int walk_node = -1;
-    // hierarchy scenes: the workgroup stages the top levels of the hierarchy in LDS once (every ray
-    // visits them; an LDS read costs a fraction of even an L1 hit and takes no vector-memory slot)
-    __shared__ f4 top_nodes[8 * 2 * kTopNodes];
-    BvhCounters bc = bvh_counters();   // hierarchy only: per-lane test counts, reduced at the end
-    if (TRI == kTriBvh) {
-        for (int oct = 0; oct < 8; ++oct) {
-            const f4 *src = (const f4 *)(S.bvh_nodes + (size_t)oct * (size_t)S.n_bvh_nodes);
-            for (int i = threadIdx.x; i < 2 * S.n_top_nodes; i += 256) top_nodes[2 * kTopNodes * oct + i] = src[i];
-        }
-        __syncthreads();
-        bc.top = (lds_f4_ptr)top_nodes; bc.n_top = S.n_top_nodes;
-    }
+    BvhCounters bc = bvh_counters();   // per-lane test counts, reduced at the end
     for (;;) {
         // ---- idle lanes take the next rays of the queue -------------------------------------------
         unsigned long long idle = __ballot(!have);
