@@ -92,7 +92,7 @@ typedef struct rt_scene_desc {
      * on them: every layout returns the same hits.  (No upstream counterpart.) */
     uint32_t flags;                /* RT_SCENE_* */
     int32_t linear_max_tris;       /* triangle count up to which the linear tables are kept (0 = 48; at most 4096) */
-    int32_t bvh_leaf_size;         /* leaf target of a hierarchy built by the library (0 = 3) */
+    int32_t bvh_leaf_size;         /* leaf target of a hierarchy built by the library (0 = 2) */
     int32_t build_threads;         /* threads of that build (0 = hardware threads, at most 16) */
 } rt_scene_desc;
 
@@ -179,7 +179,7 @@ const char *rt_last_error(const rt_ctx *ctx); /* ctx may be NULL: last error of 
 
 /* Host-side hierarchy builder (binned surface-area heuristic; CPU only, needs no context or GPU).
  * No upstream counterpart (upstream has no acceleration structure).  tri_verts = [n_tris][9] as in
- * rt_scene_desc; leaf_size = triangles per leaf to aim for (<= 0: 3).  Writes the leaf-order
+ * rt_scene_desc; leaf_size = triangles per leaf to aim for (<= 0: 2).  Writes the leaf-order
  * triangle ids to tri_index_out[n_tris], the node count to *n_nodes_out and, when nodes_out is
  * non-NULL and nodes_capacity suffices (2 * n_tris always does), the nodes.  Call with
  * nodes_out = NULL to learn the count first. */
@@ -313,9 +313,14 @@ int rt_debug_uniforms(rt_ctx *ctx, uint32_t pixel, uint32_t sample, uint64_t see
 /* How rt_set_scene laid the current scene's triangles out (no upstream counterpart; tests and tuning):
  * out[0] parallelogram rows (padded), [1] of which in general position, [2..4] compact rows per axis
  * x, y, z (padded to even), [5] single-triangle rows (padded), [6] boxes, [7] hierarchy nodes;
- * n_out >= 8; with n_out >= 9, out[8] = 1 when the last rt_set_scene refitted the hierarchy (RT_SCENE_REFIT).
+ * n_out >= 8; with n_out >= 9, out[8] = 1 when the last rt_set_scene refitted the hierarchy (RT_SCENE_REFIT);
+ * with n_out >= 10, out[9] = the stack entries the deepest walk of the wide hierarchy can ask for.
  * *box_slack (optional) = the largest distance of a true box face from its ideal one. */
 int rt_debug_scene_layout(rt_ctx *ctx, int32_t *out, int32_t n_out, float *box_slack);
+
+/* Hierarchy scenes (no upstream counterpart; tests and tuning): how many walks ran out of stack and were redone by the
+ * stackless walk of last resort since the library was loaded on this context's GPU. */
+int rt_debug_walk_fallbacks(rt_ctx *ctx, uint64_t *out);
 
 /* What the last rt_render call set aside (no upstream counterpart; tests and tuning; synchronises):
  * out4[0] the job hand-out counter, [1] paths the lean kernel set aside for the full code, [2] jobs it gave

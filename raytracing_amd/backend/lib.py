@@ -24,7 +24,7 @@ RT_ERR_STOPPED = 5
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
            "rt_comm_available", "rt_comm_unique_id", "rt_comm_init", "rt_merge",
-           "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms", "rt_debug_scene_layout", "rt_debug_render_counters",
+           "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms", "rt_debug_scene_layout", "rt_debug_walk_fallbacks", "rt_debug_render_counters",
            "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_build_bvh_threads", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
 
@@ -97,6 +97,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_debug_uniforms.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int32, fp]
     lib.rt_debug_scene_layout.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32, fp]
     lib.rt_debug_render_counters.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.rt_debug_walk_fallbacks.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.rt_debug_trace_paths.argtypes = [vp, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
                                          fp, ip, ip, ip, ip, fp, fp, fp]
     lib.rt_raytrace_batch.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_uint64,
@@ -288,11 +289,17 @@ class HipBackend:
 
     def scene_layout(self) -> dict:
         """How ``rt_set_scene`` laid the current scene's triangles out (tests and tuning)."""
-        out = (C.c_int32 * 9)()
+        out = (C.c_int32 * 10)()
         slack = C.c_float(0.0)
-        self._check(self.lib.rt_debug_scene_layout(self.handle, out, 9, C.byref(slack)))
+        self._check(self.lib.rt_debug_scene_layout(self.handle, out, 10, C.byref(slack)))
         return dict(quad_rows=out[0], quad_general=out[1], compact_rows=(out[2], out[3], out[4]), tri_rows=out[5],
-                    boxes=out[6], bvh_nodes=out[7], refitted=bool(out[8]), box_slack=float(slack.value))
+                    boxes=out[6], bvh_nodes=out[7], refitted=bool(out[8]), walk_stack_need=out[9], box_slack=float(slack.value))
+
+    def walk_fallbacks(self) -> int:
+        """Walks of the hierarchy that ran out of stack and took the stackless walk of last resort (since the library was loaded)."""
+        out = C.c_uint64(0)
+        self._check(self.lib.rt_debug_walk_fallbacks(self.handle, C.byref(out)))
+        return int(out.value)
 
     def raytrace(self, origins, directions, max_bounces: int, seed: int = 0, inside=None, first_depth: int = 0,
                  sample: int = 0, stream_begin: int = 0) -> np.ndarray:

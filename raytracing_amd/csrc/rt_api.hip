@@ -277,7 +277,7 @@ int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_
                  int32_t *tri_index_out, int32_t *n_nodes_out) {
     if (n_tris <= 0 || n_tris >= (1 << 27) || !tri_verts || !tri_index_out || !n_nodes_out || nodes_capacity < 0) return RT_ERR_INVALID_ARG;
     bvh::Builder b;
-    b.run(n_tris, tri_verts, leaf_size > 0 ? leaf_size : 3, nullptr, g_build_threads.load());
+    b.run(n_tris, tri_verts, leaf_size > 0 ? leaf_size : 2, nullptr, g_build_threads.load());
     *n_nodes_out = (int32_t)b.nodes.size();
     std::memcpy(tri_index_out, b.order.data(), sizeof(int32_t) * (size_t)n_tris);
     if ((int64_t)b.nodes.size() > nodes_capacity || !nodes_out) return nodes_out ? RT_ERR_INVALID_ARG : RT_OK;
@@ -376,8 +376,8 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             for (int t = 0; t < d->n_tris; ++t) if (!linear_tri[t]) rest.push_back(t);
             if (rest.empty()) { rest.push_back(large.back()); linear_tri[large.back()] = 0; }   // keep the hierarchy non-empty
             bvh::Builder b;
-            // leaf target: default 3 (measured 1 ... 8 on 310 ... 1.18 M triangles)
-            b.run(d->n_tris, d->tri_verts, d->bvh_leaf_size > 0 ? d->bvh_leaf_size : 3, &rest, d->build_threads);
+            // leaf target: default 2 (measured with the wide walk at 1.18 M triangles, 32 spp: 1 / 2 / 3 / 4 / 6 -> 30.1 / 30.3 / 31.1 / 34.7 / 39.1 ms)
+            b.run(d->n_tris, d->tri_verts, d->bvh_leaf_size > 0 ? d->bvh_leaf_size : 2, &rest, d->build_threads);
             bvh_nodes.swap(b.nodes); bvh_order.swap(b.order);
             c->topo_nodes = bvh_nodes; c->topo_order = bvh_order; c->topo_linear = linear_tri;
             c->topo_mesh_begin.assign(d->mesh_tri_begin, d->mesh_tri_begin + d->n_meshes + 1);
@@ -1202,7 +1202,7 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
 #ifdef RT_TUNE
     {   // tuning builds only (the shipped library reads no environment variable)
         auto num = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
-        A.tune[0] = num("RT_TUNE_SLICE", 8); A.tune[1] = num("RT_TUNE_MORE_BELOW", 16); A.tune[2] = num("RT_TUNE_MORE_TIMES", 1); A.tune[3] = 0;
+        A.tune[0] = num("RT_TUNE_SLICE", 3); A.tune[1] = num("RT_TUNE_MORE_BELOW", 32); A.tune[2] = num("RT_TUNE_MORE_TIMES", 2); A.tune[3] = num("RT_TUNE_SUB_SLICE", 3);
     }
 #endif
     // The lean kernel (no double-precision settling code, five waves per SIMD) renders; the few paths it sets
@@ -1449,6 +1449,18 @@ extern "C" int rt_debug_render_counters(rt_ctx *c, uint32_t *out4) {
     return RT_OK;
 }
 
+// How many walks gave their stack up and took the stackless walk of last resort since the library was loaded
+// on this context's GPU (tests and tuning).  Synchronises.
+extern "C" int rt_debug_walk_fallbacks(rt_ctx *c, uint64_t *out) {
+    if (!c || !out) return fail(c, RT_ERR_INVALID_ARG, "rt_debug_walk_fallbacks: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    unsigned long long v = 0;
+    HIP_TRY(c, hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_walk_fallbacks), sizeof v));
+    *out = v;
+    return RT_OK;
+}
+
 // How the current scene's triangles were laid out (tests and tuning).
 extern "C" int rt_debug_scene_layout(rt_ctx *c, int32_t *out, int32_t n_out, float *box_slack) {
     if (!c || !out || n_out < 8) return fail(c, RT_ERR_INVALID_ARG, "rt_debug_scene_layout: bad arguments");
@@ -1458,6 +1470,7 @@ extern "C" int rt_debug_scene_layout(rt_ctx *c, int32_t *out, int32_t n_out, flo
     out[2] = (int32_t)(S.slab_counts & 1023u); out[3] = (int32_t)((S.slab_counts >> 10) & 1023u); out[4] = (int32_t)(S.slab_counts >> 20);
     out[5] = S.n_tri_rows_padded; out[6] = S.n_boxes; out[7] = S.n_bvh_nodes;
     if (n_out >= 9) out[8] = c->last_refit ? 1 : 0;
+    if (n_out >= 10) out[9] = c->walk_stack_need;
     if (box_slack) *box_slack = S.box_slack;
     return RT_OK;
 }

@@ -62,6 +62,11 @@ RT_DEV float min_(float a, float b) { return __builtin_fminf(a, b); }
 RT_DEV float max_(float a, float b) { return __builtin_fmaxf(a, b); }
 RT_DEV float abs_(float a) { return __builtin_fabsf(a); }
 RT_DEV uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// lane number within the wave; number of set bits of `mask` below this lane
+RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+RT_DEV uint32_t rank_in(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 RT_DEV uint32_t umed3_(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -733,7 +738,8 @@ RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
 // harm (a first pass that sees a candidate twice finds a runner-up at the winner's depth and settles the query in
 // double precision).
 // ---------------------------------------------------------------------------------------------
-__shared__ uint32_t g_walk_lds[4 * (kWalkStack + kWalkPending) * 64];   // [wave of the workgroup][entry][lane]; 32 KB
+__device__ unsigned long long g_walk_fallbacks;   // walks of last resort since the library was loaded (rt_debug_walk_fallbacks)
+__shared__ uint32_t g_walk_lds[4 * kWalkColumn * 64];   // [wave of the workgroup][entry][lane]; 32 KB
 
 // Per-query walk context: test counters.
 struct BvhCounters { uint32_t nodes, tris; };
@@ -801,10 +807,10 @@ RT_DEV void walk_threaded(SceneRef S, const Ray &r, const WalkRay &w, Sink &sink
 // finish early can take new work instead of idling until the slowest ray of the wave (one that grazes a dense mesh
 // visits ten times the average) is through.  The lane's stack lives in its column of g_walk_lds from one call to the
 // next; nothing else may walk on this lane in between.
-constexpr int kSubSlice = 3;   // nodes a lane visits between two rounds of triangle tests
+constexpr int kSubSlice = 4;   // nodes a lane visits between two rounds of triangle tests
 
 template <class Sink>
-RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, int &state, int budget) {
+RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, int &state, int budget, int sub_slice = kSubSlice) {
     const WalkRay w = walk_ray<Sink::kPerTriangle>(S, r);
     const int oct = (r.dx < 0.0f ? 1 : 0) | (r.dy < 0.0f ? 2 : 0) | (r.dz < 0.0f ? 4 : 0);
     const uint32_t order_shift = 8u * (uint32_t)(oct & 3);
@@ -812,7 +818,7 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
     const f4 *nodes = (const f4 *)S.wide_nodes;
     const TriRow *rows = S.leaf_rows;
     // this lane's column: stack entries 0 .. kWalkStack - 1, then the pending leaves
-    uint32_t *const col = g_walk_lds + ((threadIdx.x >> 6) * (kWalkStack + kWalkPending)) * 64 + (threadIdx.x & 63);
+    uint32_t *const col = g_walk_lds + ((threadIdx.x >> 6) * kWalkColumn) * 64 + (threadIdx.x & 63);
     uint32_t *const pend_col = col + kWalkStack * 64;
     const int cap = S.walk_stack;
     int cur = S.n_bvh_nodes > 0 ? (state < 0 ? -1 : (state & 0xFFFFFF)) : -1;
@@ -820,7 +826,7 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
     int visited = 0;
     bool overflow = false;
     while (visited < budget && cur >= 0) {
-        const int stop = visited + kSubSlice < budget ? visited + kSubSlice : budget;
+        const int stop = visited + sub_slice < budget ? visited + sub_slice : budget;
         int pend = 0;
         // The body is written without branches (selects, and stores whose address moves on only when they count):
         // as nested ifs such a body compiles to more scalar mask and branch instructions than the box tests take.
@@ -871,14 +877,15 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
         PROF(kProfWalk);
         if (pend > 0) {
             // the pending leaves' triangles, oldest leaf first: candidates reach the sink in the order the walk met them
+            // (among candidates with equal lower bounds - 0 for everything that starts behind the origin - the sink
+            // keeps the first, so how a query gets settled, though not its result, depends on that order)
             int e = 0, k = 0;
             uint32_t desc = pend_col[0];
             while (e < pend) {
                 PROF_LANES(kProfLeafIters, (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__ballot(1))); PROF_LANES(kProfLeafLanes, true);
-                const int cnt = (int)(desc & 15u);
                 test_leaf_row(rows, (int)(desc >> 4) + k, r, sink); bc.tris += 1u;
                 ++k;
-                const bool next = k >= cnt;
+                const bool next = k >= (int)(desc & 15u);
                 e += next ? 1 : 0; k = next ? 0 : k;
                 desc = pend_col[64 * (e < kWalkPending ? e : kWalkPending - 1)];
             }
@@ -888,7 +895,7 @@ RT_DEV void search_bvh(SceneRef S, const Ray &r, Sink &sink, BvhCounters &bc, in
     }
     state = cur < 0 ? -1 : (cur | (sp << 24));
     if (__ballot(overflow) != 0) {
-        if (overflow) walk_threaded(S, r, w, sink, bc);
+        if (overflow) { atomicAdd(&g_walk_fallbacks, 1ull); walk_threaded(S, r, w, sink, bc); }
     }
 }
 

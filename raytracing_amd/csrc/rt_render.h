@@ -281,10 +281,6 @@ RT_DEV uint32_t fast_div(uint32_t n, const FastDiv &f) {
     return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
-RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-RT_DEV uint32_t rank_in(unsigned long long mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 
 // The job-bookkeeping members of RenderArgs (rectangle, sample range, divisors, output pointers) are
 // needed a few times per JOB, not per path segment.  Read as ordinary by-value kernel arguments they
@@ -300,7 +296,7 @@ RT_DEV KernargRenderArgs kernarg_render_args() {
 }
 
 constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at a time
-constexpr int kWalkSlice = 3;   // wide nodes (four boxes each) a lane visits per trip of the render loop (hierarchy scenes)
+constexpr int kWalkSlice = 4;   // wide nodes (four boxes each) a lane visits per trip of the render loop (hierarchy scenes)
 
 // STRICT: a float32 hit depth is accepted only under the closest-hit entry's error bound (9.5e-6
 // relative) instead of the render's looser one (see kRelAcceptRender); hit identity is the same.
@@ -318,8 +314,11 @@ constexpr int kWalkSlice = 3;   // wide nodes (four boxes each) a lane visits pe
 #ifndef RT_LEAN_WAVES
 #define RT_LEAN_WAVES 5   // waves per SIMD the lean kernel is compiled for (measured: see the table in the design notes)
 #endif
+#ifndef RT_BVH_FOUR_WAVES
+#define RT_BVH_FOUR_WAVES (-1)   // set to kTriBvh: the lean kernel of hierarchy scenes is compiled for four waves per SIMD too
+#endif
 template <int TRI, bool HAS_SPH, bool STRICT, bool LEAN>
-__global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const DevScene S_arg, const RenderArgs A) {
+__global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_WAVES : 4) void k_render(const DevScene S_arg, const RenderArgs A) {
     SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     // wave-uniform job window
     uint32_t win_next = 0, win_end = 0;
@@ -467,13 +466,13 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
                     if (ray_route<TRI>(ray) == kRouteFilter) { hit_begin<TRI, HAS_SPH>(S, ray, rr, first); walk_node = 0; }
                 }
 #ifdef RT_TUNE
-                const int walk_slice = A.tune[0], more_below = A.tune[1], more_times = A.tune[2];
+                const int walk_slice = (!LEAN && JOB(path_mode)) ? 4 * A.tune[0] : A.tune[0], more_below = A.tune[1], more_times = A.tune[2], sub_slice = A.tune[3];
 #else
                 // (path mode: every lane holds a path that went deep or grazed something - longer slices, fewer trips)
                 const int walk_slice = (!LEAN && JOB(path_mode)) ? 4 * kWalkSlice : kWalkSlice;
-                constexpr int more_below = 32, more_times = 2;
+                constexpr int more_below = 32, more_times = 2, sub_slice = kSubSlice;
 #endif
-                if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
+                if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice, sub_slice);
                 // When only a few lanes are through, closing their queries now would run ~1,000
                 // instructions for them alone: the wave walks another slice first, up to twice, while fewer than half
                 // its lanes are through.  (Measured at 1.18 M triangles, kernel time for 32 samples per pixel: no
@@ -484,11 +483,11 @@ __global__ __launch_bounds__(256, LEAN ? RT_LEAN_WAVES : 4) void k_render(const 
                     // 1.18 M triangles, 780 k paths set aside: 6.4 ms; going on once three lanes in four are through:
                     // 6.5; slices and lane-by-lane refill as in the lean kernel: 7.4)
                     while (__ballot(walk_node >= 0) != 0) {
-                        if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
+                        if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice, sub_slice);
                     }
                 } else
                 for (int k = 0; k < more_times && __builtin_popcountll(__ballot(walk_node < 0)) < more_below; ++k) {
-                    if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice);
+                    if (walk_node >= 0) search_bvh(S, ray, first, bc, walk_node, walk_slice, sub_slice);
                 }
                 PROF_LANES(kProfLanesEnd, walk_node < 0);
                 if (walk_node < 0) {

@@ -121,8 +121,13 @@ struct WideNode {
     uint32_t order[2]; int32_t first; uint32_t inner;
 };
 static_assert(sizeof(WideNode) == 128, "WideNode: one 128-byte line");
-constexpr int kWalkStack = 24;     // entries of a lane's stack of wide nodes still to visit (LDS)
-constexpr int kWalkPending = 8;    // leaves a lane may hold before its triangles are tested (LDS, after the stack)
+// A wave's share of the walk's LDS: kWalkColumn rows of 64 dwords, a column per lane.
+#ifndef RT_WALK_STACK
+#define RT_WALK_STACK 20
+#endif
+constexpr int kWalkStack = RT_WALK_STACK;   // rows 0 .. : a lane's stack of wide nodes still to visit
+constexpr int kWalkPending = 8;             // then: leaves a lane holds until their triangles are tested
+constexpr int kWalkColumn = kWalkStack + kWalkPending;
 
 // Scene data only the rare double-precision code, the depth-of-field camera and the ray-generation
 // kernel read.  It lives in device memory behind DevScene::cold, so that the render kernel does not

@@ -25,4 +25,4 @@ for lv, bvh, spp in cases:
         if best is None or st["kernel_ms"] < best["kernel_ms"]: best = st
     st = best
     print(f"tris {sc.n_tris:8d} bvh={int(bvh)} set_scene {t_set:.2f}s {spp}spp kernel {st['kernel_ms']:.2f} ms  {st['rays']/st['kernel_ms']/1e6:.3f} Grays/s  "
-          f"nodes/ray {st['bvh_node_tests']/st['rays']:.1f} tris/ray {st['tri_tests']/st['rays']:.1f} exact={st['exact_rays']/st['rays']:.2e} refine={st['refined_hits']/st['rays']:.3f}", flush=True)
+          f"stack need {be.scene_layout()['walk_stack_need']} fallbacks {be.walk_fallbacks()} nodes/ray {st['bvh_node_tests']/st['rays']:.1f} tris/ray {st['tri_tests']/st['rays']:.1f} exact={st['exact_rays']/st['rays']:.2e} refine={st['refined_hits']/st['rays']:.3f}", flush=True)

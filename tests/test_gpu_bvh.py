@@ -154,6 +154,42 @@ def test_subdivided_mesh_against_oracle(backend, levels, n_path, n_rand):
     assert (np.abs(got["t"][both] - coarse["t"][both]) > 1e-5 * np.maximum(coarse["t"][both], 1e-3)).mean() < 0.01
 
 
+def test_walk_of_last_resort(backend, monkeypatch):
+    """A lane whose stack of wide nodes runs full walks the threaded two-child hierarchy without a stack instead.
+    With the stack cut to six entries (RT_SCENE_TINY_WALK_STACK) most walks that enter the 74 k-triangle mesh
+    do: hits still equal the oracle's, closest-hit entry and whole paths alike, and with the full stack
+    (the builder reports what the deepest walk can need) the same rays never take that road."""
+    base = h.packed_scene("room_horse")
+    sc = base.with_subdivided_mesh(base.n_meshes - 1, 4)
+    z, o32, d32 = _path_rays()
+    o32, d32 = o32[:6000], d32[:6000]
+    o, d = _random_rays(4000, 77)
+    want_path, want_rand = h.oracle_intersect(sc, o32, d32), h.oracle_intersect(sc, o, d)
+    backend.set_scene(sc)
+    assert backend.scene_layout()["walk_stack_need"] > 6
+    before = backend.walk_fallbacks()
+    _check_hits(backend.intersect(o32, d32), want_path)
+    assert backend.walk_fallbacks() == before, "the full stack overflowed on the test's rays"
+    monkeypatch.setenv("RAYTRACING_AMD_TINY_WALK_STACK", "1")
+    backend.set_scene(sc)
+    monkeypatch.delenv("RAYTRACING_AMD_TINY_WALK_STACK")
+    _check_hits(backend.intersect(o32, d32), want_path)
+    _check_hits(backend.intersect(o, d), want_rand)
+    assert backend.walk_fallbacks() > before + 100, "the tiny stack never overflowed: the test exercises nothing"
+    # whole paths through the render path's own device functions
+    W, H, b = 64, 36, 3
+    rng = np.random.default_rng(5)
+    xys = np.stack([rng.integers(20, 60, 60), rng.integers(2, 30, 60), np.zeros(60, np.int64)], 1).astype(np.int32)
+    tr = backend.trace_paths(xys, W, H, b, h.SEED_RENDER)
+    bad = 0
+    with h.origin_rule():
+        for i, (x, y, s_) in enumerate(xys):
+            want = h.oracle_trace_pixel(sc, W, H, int(x), int(y), int(s_), b)[0]
+            bad += not np.allclose(tr["rgb"][i], want, rtol=2e-3, atol=2e-4)
+    assert bad <= 1, f"{bad} of {len(xys)} paths differ"
+    backend.set_scene(sc)   # (the module's other tests get the full stack back)
+
+
 def test_render_hierarchy_equals_linear_walk(backend):
     """Same image from the linear walk and from the hierarchy (310 triangles, both supported):
     identical hits give identical paths; only which hits get a double-precision refinement may
@@ -199,8 +235,8 @@ def test_render_large_mesh_against_oracle_paths(backend):
 
 
 def test_render_rectangle_of_large_mesh_against_oracle(backend):
-    """rt_render ITSELF at 1.18 M triangles - the lean kernel with its sliced, resumable walk, the top levels of
-    the hierarchy in LDS, the held leaves, the set-aside paths and the launch that finishes them - against the
+    """rt_render ITSELF at 1.18 M triangles - the lean kernel with its sliced, resumable walk of the wide hierarchy,
+    the per-lane stack and pending leaves in LDS, the set-aside paths and the launch that finishes them - against the
     oracle's brute-force render of the same rectangle (origin rule, same sample sequence).  The rectangle is
     put on the mesh's silhouette, where paths graze the dense mesh.  Pixels agree to float32 rounding; at most
     two may differ (a path that runs along an edge of the room can pick the other face with float32 origins)."""
