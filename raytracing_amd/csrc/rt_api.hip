@@ -105,7 +105,7 @@ struct rt_ctx {
     DevBuf aside, aside_head, dirty, dirty_list;   // rt_render: paths set aside by the lean kernel, jobs it gave up (grow-only)
     DevBuf post_partials;   // rt_postprocess: per-block reduction slots
     double *post_scratch = nullptr;   // rt_postprocess_noalloc: this GPU's copy of the static scratch array
-    DevBuf wf_rays[2], wf_paths, wf_hits, wf_radiance, wf_counters, wf_partials;   // wavefront form (hierarchy scenes)
+    DevBuf wf_rays[2], wf_paths, wf_hits, wf_radiance, wf_counters, wf_partials, wf_settle;   // wavefront form (hierarchy scenes)
     DevBuf ray_dir, ray_res; int ray_w = 0, ray_h = 0;   // camera-ray table of the current scene at ray_w x ray_h
     // The hierarchy rt_set_scene last BUILT (host copy: threaded depth-first nodes, leaf order, which triangles stay in
     // the linear tables) and what it was built for: a later scene that differs only in vertex positions can be
@@ -1079,7 +1079,7 @@ int render_wavefront(rt_ctx *c, const rt_render_params *p, float *accum, hipStre
     bool grow = false;
     for (int k = 0; k < 2; ++k) grow = grow || cap_paths * sizeof(WfRay) > c->wf_rays[k].bytes;
     const size_t n_part_rows = (cap_paths + 255) / 256;
-    grow = grow || cap_paths * sizeof(WfPath) > c->wf_paths.bytes || (size_t)(2 * (n_seg + 1)) * 4 > c->wf_counters.bytes ||
+    grow = grow || cap_paths * sizeof(WfPath) > c->wf_paths.bytes || (size_t)(3 * (64 + 1)) * 4 > c->wf_counters.bytes || cap_paths * 4 > c->wf_settle.bytes ||
            n_part_rows * kStatCount * 8 > c->wf_partials.bytes;
     if (grow) {
         HIP_TRY(c, hipDeviceSynchronize());   // earlier launches may still use the old buffers
@@ -1087,7 +1087,8 @@ int render_wavefront(rt_ctx *c, const rt_render_params *p, float *accum, hipStre
         HIP_TRY(c, c->wf_paths.ensure(cap_paths * sizeof(WfPath)));
         HIP_TRY(c, c->wf_hits.ensure(cap_paths * sizeof(WfHit)));
         HIP_TRY(c, c->wf_radiance.ensure(cap_paths * 3 * sizeof(float)));
-        HIP_TRY(c, c->wf_counters.ensure((size_t)(2 * (64 + 1)) * 4));
+        HIP_TRY(c, c->wf_counters.ensure((size_t)(3 * (64 + 1)) * 4));
+        HIP_TRY(c, c->wf_settle.ensure(cap_paths * 4));
         HIP_TRY(c, c->wf_partials.ensure(n_part_rows * kStatCount * 8));
         HIP_TRY(c, hipMemset(c->wf_partials.p, 0, c->wf_partials.bytes));
     }
@@ -1101,6 +1102,7 @@ int render_wavefront(rt_ctx *c, const rt_render_params *p, float *accum, hipStre
     const DevScene S = c->S;
     uint32_t *counts = c->wf_counters.as<uint32_t>();          // [n_seg + 1] rays queued per segment
     uint32_t *cursors = counts + (64 + 1);                      // [n_seg] extend's read position per segment
+    uint32_t *settles = cursors + (64 + 1);                     // [n_seg] queries per segment that k_wf_settle has to close
     for (int s0 = 0; s0 < p->sample_count; s0 += batch_cap) {
         const int bs = std::min(batch_cap, p->sample_count - s0);
         WfArgs A{};
@@ -1111,17 +1113,24 @@ int render_wavefront(rt_ctx *c, const rt_render_params *p, float *accum, hipStre
         A.max_bounces = p->max_bounces; A.seed_lo = (uint32_t)p->seed; A.seed_hi = (uint32_t)(p->seed >> 32);
         A.paths = c->wf_paths.as<WfPath>(); A.hits = c->wf_hits.as<WfHit>(); A.radiance = c->wf_radiance.as<float>();
         A.accum = accum; A.stats = c->stats.as<unsigned long long>(); A.partials = c->wf_partials.as<unsigned long long>();
-        HIP_TRY(c, hipMemsetAsync(counts, 0, (size_t)(2 * (64 + 1)) * 4, stream));
+        HIP_TRY(c, hipMemsetAsync(counts, 0, (size_t)(3 * (64 + 1)) * 4, stream));
         const unsigned path_blocks = (unsigned)((A.n_paths + 255) / 256);
         A.rays_in = c->wf_rays[0].as<WfRay>(); A.rays_out = c->wf_rays[1].as<WfRay>();
         A.count_in = counts; A.count_out = counts + 1; A.cursor = cursors;
+        A.settle_list = c->wf_settle.as<uint32_t>(); A.settle_count = settles;
         hipLaunchKernelGGL(k_wf_generate, dim3(path_blocks), dim3(256), 0, stream, S, A);
-        const unsigned extend_blocks = std::min<unsigned>(path_blocks, (unsigned)c->n_cu * 3u);
+        const unsigned extend_blocks = std::min<unsigned>(path_blocks, (unsigned)c->n_cu * 5u);
         for (int seg = 0; seg < n_seg; ++seg) {
             A.rays_in = c->wf_rays[seg & 1].as<WfRay>(); A.rays_out = c->wf_rays[(seg + 1) & 1].as<WfRay>();
-            A.count_in = counts + seg; A.count_out = counts + seg + 1; A.cursor = cursors + seg;
-            if (c->has_sph) hipLaunchKernelGGL((k_wf_extend<true>), dim3(extend_blocks), dim3(256), 0, stream, S, A);
-            else hipLaunchKernelGGL((k_wf_extend<false>), dim3(extend_blocks), dim3(256), 0, stream, S, A);
+            A.count_in = counts + seg; A.count_out = counts + seg + 1; A.cursor = cursors + seg; A.settle_count = settles + seg;
+            const unsigned settle_blocks = std::min<unsigned>(path_blocks, (unsigned)c->n_cu * 4u);
+            if (c->has_sph) {
+                hipLaunchKernelGGL((k_wf_extend<true>), dim3(extend_blocks), dim3(256), 0, stream, S, A);
+                hipLaunchKernelGGL((k_wf_settle<true>), dim3(settle_blocks), dim3(256), 0, stream, S, A);
+            } else {
+                hipLaunchKernelGGL((k_wf_extend<false>), dim3(extend_blocks), dim3(256), 0, stream, S, A);
+                hipLaunchKernelGGL((k_wf_settle<false>), dim3(settle_blocks), dim3(256), 0, stream, S, A);
+            }
             hipLaunchKernelGGL(k_wf_shade, dim3(path_blocks), dim3(256), 0, stream, S, A);
         }
         hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)((rect_px + 255) / 256)), dim3(256), 0, stream, A);

@@ -1,31 +1,30 @@
-// Wavefront form of the render path for scenes searched through the hierarchy (optional: selected
-// with RAYTRACING_AMD_WAVEFRONT=1; the single kernel of rt_render.h is the default because it
-// measures faster - see the note at the end of this comment).
+// Wavefront form of the render path for scenes searched through the hierarchy (optional: RT_RENDER_WAVEFRONT;
+// the single-kernel pipeline of rt_render.h is the default because it measures faster - see the end of this comment).
 //
-// The single render kernel keeps a whole path in registers; every trip of its loop strings a dozen
-// dependent per-lane loads (boxes, leaf rows, the winner's rows, material, sky texel) with only three
-// waves per SIMD to hide them.  Here the path is cut at the closest-hit query:
+// The single render kernel keeps a whole path in registers.  Here the path is cut at the closest-hit query and the
+// rays of one path segment are worked on queue by queue:
 //
 //   k_wf_generate   camera rays of a batch of paths (Camera.get_ray, camera.py:39-50)
-//   k_wf_extend     closest hit of every queued ray (Scene.intersect, scene.py:23-27) - a lean,
-//                   persistent kernel: lanes take rays from the queue one by one and walk the
-//                   hierarchy in slices, so a lane whose ray is done takes the next ray at once
-//   k_wf_shade      environment or one bounce per answered ray (renderer.py:39-79); surviving
-//                   paths append their next ray to the other queue, finished ones store radiance
-//   k_wf_resolve    per pixel, adds the batch's path radiances to the accumulation buffer in
-//                   sample order (deterministic: no floating-point atomics anywhere)
+//   k_wf_extend     closest hit of every queued ray (Scene.intersect, scene.py:23-27) - a LEAN, persistent kernel
+//                   (no double-precision settling code: five waves per SIMD): lanes take rays from the queue one by
+//                   one and walk the hierarchy in slices, so a lane whose ray is done takes the next ray at once; a
+//                   query the float32 code cannot answer alone goes, with its first pass's result, on a second list
+//   k_wf_settle     those queries: judged and settled in double precision (hit_finish, the full form)
+//   k_wf_shade      environment or one bounce per answered ray (renderer.py:39-79), MATERIAL-SORTED: the 256 rays of
+//                   a workgroup are regrouped by what they hit (environment, then by object = by material) with a
+//                   counting sort in LDS before they are shaded, so the lanes of a wave run the same material's
+//                   branch of renderer.py:45-70 and read the same MatRow; surviving paths append their next ray to
+//                   the other queue, finished ones store their radiance
+//   k_wf_resolve    per pixel, adds the batch's path radiances to the accumulation buffer in sample order
+//                   (deterministic: no floating-point atomics anywhere)
 //
-// and the host runs extend + shade once per path segment.  Path state lives in HBM between the
-// kernels (32-byte ray, 32-byte path, 48-byte hit record: ~150 bytes moved per segment, far from
-// the HBM bound).  The device functions - camera_ray, closest hit, path_shade - are the ones the
-// single kernel uses, so both forms trace identical paths.
+// and the host runs extend + settle + shade once per path segment.  Path state lives in HBM between the kernels
+// (32-byte ray, 32-byte path, 48-byte hit record: ~150 bytes moved per segment, far from the HBM bound).  The device
+// functions - camera_ray, hit_begin / search_bvh / hit_finish, path_shade - are the ones the single kernel uses, so
+// both forms trace identical paths.  Same-address atomics cost ~8 ns each on this GPU: queue appends and statistics
+// are aggregated per wave or per block.
 //
-// Measured (room + 1.18 M triangles, 1080p, 32 spp, 8 bounces, G rays/s): single kernel 4.1;
-// wavefront 1.4 / 2.7 / 3.3 with 4 M / 16 M / 64 M paths per batch.  Two reasons: every extend
-// launch ends with each wave waiting for its own slowest lanes (amortised only by very large
-// batches), and the extend kernel is not lean - with the double-precision settling code inlined it
-// needs 161 VGPRs, the same three waves per SIMD as the single kernel.  Same-address atomics cost
-// ~8 ns each on this GPU: queue appends and statistics are therefore aggregated per block.
+// Measured: see the design notes (wavefront against single-kernel pipeline on the 1.18 M-triangle scene).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -39,7 +38,7 @@ struct WfHit {   // 48 B
     float nx, ny, nz; int32_t obj;
     float px, py, pz; int32_t gprim;
     uint32_t flags;   // bit 0: contenders settled in double precision, bit 1: winner re-evaluated in double precision
-    uint32_t pad0, pad1, pad2;
+    uint32_t first[3];   // a query on the settle list: its first pass's result (PairBest::lo0, lo1, id0 as bits)
 };
 
 struct WfArgs {
@@ -56,6 +55,7 @@ struct WfArgs {
     WfHit *hits;
     float *radiance;             // [n_paths][3]
     uint32_t *count_in, *count_out, *cursor;   // device words: rays queued for this / the next segment, extend's read cursor
+    uint32_t *settle_list, *settle_count;      // queue positions of the rays whose query k_wf_settle has to close, and their number
     float *accum;
     unsigned long long *stats;
     unsigned long long *partials;   // [blocks][kStatCount] per-block statistics, folded by k_wf_fold_stats (no hot atomics)
@@ -90,7 +90,7 @@ constexpr int kWfGrab = 256;    // rays a wave reserves from the queue at a time
                                  // same-address atomics complete at only ~0.1 G/s)
 
 template <bool HAS_SPH>
-__global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, const WfArgs A) {
+__global__ __launch_bounds__(256, 5) void k_wf_extend(const DevScene S_arg, const WfArgs A) {
     SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
     constexpr int TRI = kTriBvh;
     const uint32_t total = *A.count_in;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, cons
     bool drained = false;
     bool have = false, walking = false;
     WfRay ray; ray.ox = ray.oy = ray.oz = 0; ray.dx = ray.dy = 0; ray.dz = 1; ray.origin = -1; ray.path = 0;
-    uint32_t pixel = 0; int32_t depth = 0;
+    uint32_t pixel = 0, slot = 0; int32_t depth = 0;
     typename FirstPass<TRI>::type first;
     first.init(S);
     int walk_node = -1;
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, cons
             const uint32_t avail = win_end - win_next;
             const uint32_t rk = rank_in(idle);
             if (!have && rk < avail) {
-                ray = A.rays_in[win_next + rk];
+                slot = win_next + rk;
+                ray = A.rays_in[slot];
                 const WfPath s = A.paths[ray.path];
                 pixel = s.pixel; depth = s.depth;
                 have = true; walking = false;
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, cons
             idle = __ballot(!have);
         }
         if (__ballot(have) == 0) break;
+        bool to_settle = false;
         if (have) {
             const Ray r = make_ray(S, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, ray.origin, depth == 0, origin_tag(S, ray.origin));
             RayResidue rr;
@@ -140,16 +142,24 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, cons
             }
             if (walk_node >= 0) search_bvh(S, r, first, bc, walk_node, kWfSlice);
             if (walk_node < 0) {
-                BvhCounters second_pass = bc; second_pass.nodes = 0; second_pass.tris = 0;
-                const Hit h = hit_finish<TRI, HAS_SPH, true>(S, r, rr, first, second_pass, nullptr);
-                bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
+                const Hit h = hit_finish<TRI, HAS_SPH, true, true>(S, r, rr, first, bvh_counters(), nullptr);
                 WfHit w;
                 w.nx = h.nx; w.ny = h.ny; w.nz = h.nz; w.obj = h.obj;
                 w.px = h.px; w.py = h.py; w.pz = h.pz; w.gprim = h.gprim;
-                w.flags = (h.how == 2 ? 1u : 0u) | (h.refined ? 2u : 0u); w.pad0 = w.pad1 = w.pad2 = 0;
+                w.flags = h.refined ? 2u : 0u;
+                w.first[0] = f2u(first.lo0); w.first[1] = f2u(first.lo1); w.first[2] = (uint32_t)first.id0;
                 A.hits[ray.path] = w;
+                to_settle = h.how == kHowDeferred;
                 have = false; walking = false;
             }
+        }
+        // queries for k_wf_settle: one counter bump per wave
+        const unsigned long long sm = __ballot(to_settle);
+        if (sm != 0) {
+            uint32_t base = 0;
+            if (lane_id() == (uint32_t)__builtin_ctzll(sm)) base = atomicAdd(A.settle_count, (uint32_t)__builtin_popcountll(sm));
+            base = (uint32_t)__shfl((int)base, __builtin_ctzll(sm), 64);
+            if (to_settle) A.settle_list[base + rank_in(sm)] = slot;
         }
     }
     // statistics: per-block sums into the block's own row of `partials` (launches on one stream
@@ -167,10 +177,70 @@ __global__ __launch_bounds__(256, 3) void k_wf_extend(const DevScene S_arg, cons
     }
 }
 
+// The queries the lean extend kernel could not close: each goes on from its first pass's result (as the single-kernel
+// pipeline's set-aside paths do) through the full hit_finish - judge, double-precision settling, second walk.
+template <bool HAS_SPH>
+__global__ __launch_bounds__(256) void k_wf_settle(const DevScene S_arg, const WfArgs A) {
+    SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
+    constexpr int TRI = kTriBvh;
+    const uint32_t n = *A.settle_count;
+    BvhCounters bc = bvh_counters();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const WfRay ray = A.rays_in[A.settle_list[i]];
+        const WfPath s = A.paths[ray.path];
+        WfHit w = A.hits[ray.path];
+        const Ray r = make_ray(S, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, ray.origin, s.depth == 0, origin_tag(S, ray.origin));
+        RayResidue rr;
+        rr.table = A.ray_res; rr.pixel = s.pixel; rr.on = (s.depth == 0) && !S.dof_on;
+        typename FirstPass<TRI>::type first;
+        first.init(S);
+        first.lo0 = u2f(w.first[0]); first.lo1 = u2f(w.first[1]); first.id0 = (int32_t)w.first[2];
+        const Hit h = hit_finish<TRI, HAS_SPH, true, false>(S, r, rr, first, bvh_counters(), nullptr);
+        bc.nodes += h.bvh_nodes; bc.tris += h.bvh_tris;
+        w.nx = h.nx; w.ny = h.ny; w.nz = h.nz; w.obj = h.obj;
+        w.px = h.px; w.py = h.py; w.pz = h.pz; w.gprim = h.gprim;
+        w.flags = (h.how == 2 ? 1u : 0u) | (h.refined ? 2u : 0u);
+        A.hits[ray.path] = w;
+    }
+    // (second walks are counted like the first: per-block sums, one plain update of the block's own row)
+    __shared__ unsigned long long sh_nodes[4], sh_tris[4];
+    unsigned long long nodes = bc.nodes, tris = bc.tris;
+    for (int off = 32; off > 0; off >>= 1) { nodes += __shfl_down(nodes, off, 64); tris += __shfl_down(tris, off, 64); }
+    const int wave = threadIdx.x >> 6;
+    if (lane_id() == 0) { sh_nodes[wave] = nodes; sh_tris[wave] = tris; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *row = A.partials + (size_t)blockIdx.x * kStatCount;
+        row[kStatBvhNodes] += sh_nodes[0] + sh_nodes[1] + sh_nodes[2] + sh_nodes[3];
+        row[kStatTriTests] += sh_tris[0] + sh_tris[1] + sh_tris[2] + sh_tris[3];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_wf_shade(const DevScene S_arg, const WfArgs A) {
     SceneRef S = *kernarg_scene();   // the scene argument, read in place (scalar loads)
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = *A.count_in;
+    // Material sort: the workgroup's 256 rays are regrouped by what they hit - the environment first, then by
+    // object (every object has its own MatRow) - with a counting sort in LDS, and thread t shades the ray at sorted
+    // position t.  Which ray a thread shades changes nothing in the ray's result; it changes which lanes share a
+    // wave: lanes that read the same material and take the same branch of renderer.py:45-70.
+    constexpr int kBins = 18;   // environment, objects 0 .. 15 (higher ones share the last bin), no ray
+    __shared__ uint32_t sort_hist[kBins], sort_base[kBins];
+    __shared__ uint16_t sort_perm[256];
+    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    int key = kBins - 1;
+    if (i0 < total) {
+        const int32_t obj = A.hits[A.rays_in[i0].path].obj;
+        key = obj < 0 ? 0 : (obj < 16 ? obj + 1 : 16);
+    }
+    if (threadIdx.x < kBins) sort_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t in_bin = atomicAdd(&sort_hist[key], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int k = 0; k < kBins; ++k) { sort_base[k] = run; run += sort_hist[k]; } }
+    __syncthreads();
+    sort_perm[sort_base[key] + in_bin] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + sort_perm[threadIdx.x];
     const bool live = i < total;
     bool alive = false, f_exact = false, f_refine = false, f_sky = false, f_shaded = false, f_done = false;
     WfRay next; next.ox = next.oy = next.oz = 0; next.dx = next.dy = next.dz = 0; next.origin = -1; next.path = 0;
@@ -185,7 +255,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const DevScene S_arg, const Wf
         p.depth = s.depth; p.origin = ray.origin; p.inside = s.inside != 0; p.pixel = s.pixel;
         Hit h;
         h.obj = w.obj; h.prim = 0; h.gprim = w.gprim; h.t = 0; h.nx = w.nx; h.ny = w.ny; h.nz = w.nz;
-        h.px = w.px; h.py = w.py; h.pz = w.pz; h.how = 0; h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0;
+        h.px = w.px; h.py = w.py; h.pz = w.pz; h.how = 0; h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0; h.tag = 0u; h.own_ratio = kInf;
         float er, eg, eb;
         uint32_t sky_unused = 0;   // (this kernel counts from its own flags)
         alive = path_shade(S, p, A.max_bounces, h, er, eg, eb, sky_unused);
