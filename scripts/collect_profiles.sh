@@ -3,8 +3,9 @@
 #   bash scripts/collect_profiles.sh <tag>
 # 1. rocprofv3 --kernel-trace --stats over bench.py (kernel durations);
 # 2. PMC passes, each a run of its own: HBM read bytes, HBM written bytes, SQ instruction mix, SQ activity -
-#    over one 256-spp room launch (the bench workload's launch) and over the 1.18 M-triangle scene.
-# Results under gpurun_out/prof_<tag>/; scripts/compose_counters.py turns them into profiles/*.json.
+#    over one 256-spp room launch (the bench workload's launch), one 64-spp launch of the spheres scene (BASELINE
+#    configs[1]) and one 16-spp launch of the 1.18 M-triangle scene.
+# Results under gpurun_out/prof_<tag>/; scripts/compose_counters.py turns them into profiles/<round>_*.json.
 set -e
 tag=$1
 repo=${GRAFT_REPO_ROOT:-/root/repo}
@@ -27,8 +28,14 @@ CNT="WRITE_SIZE" pass room_write $repo/scripts/prof_room.py room 256
 CNT="$SQ_A" pass room_sq_a $repo/scripts/prof_room.py room 256
 CNT="$SQ_B" pass room_sq_b $repo/scripts/prof_room.py room 256
 CNT="$SQ_C" pass room_sq_c $repo/scripts/prof_room.py room 256
+CNT="FETCH_SIZE" pass spheres_fetch $repo/scripts/prof_room.py random_spheres_seed7 64
+CNT="WRITE_SIZE" pass spheres_write $repo/scripts/prof_room.py random_spheres_seed7 64
+CNT="$SQ_A" pass spheres_sq_a $repo/scripts/prof_room.py random_spheres_seed7 64
+CNT="$SQ_B" pass spheres_sq_b $repo/scripts/prof_room.py random_spheres_seed7 64
+CNT="$SQ_C" pass spheres_sq_c $repo/scripts/prof_room.py random_spheres_seed7 64
 CNT="FETCH_SIZE" pass bvh_fetch $repo/scripts/prof_bvh.py 6 16
 CNT="WRITE_SIZE" pass bvh_write $repo/scripts/prof_bvh.py 6 16
 CNT="$SQ_A" pass bvh_sq_a $repo/scripts/prof_bvh.py 6 16
 CNT="$SQ_B" pass bvh_sq_b $repo/scripts/prof_bvh.py 6 16
+CNT="$SQ_C" pass bvh_sq_c $repo/scripts/prof_bvh.py 6 16
 CNT="$TC_A" pass bvh_tc_a $repo/scripts/prof_bvh.py 6 16

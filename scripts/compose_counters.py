@@ -1,10 +1,11 @@
 """Turn the passes of scripts/collect_profiles.sh into the counter files bench.py reads (developer tool):
-    python scripts/compose_counters.py <tag>      -> profiles/r2_room_counters.json, profiles/r2_bvh_counters.json,
-                                                     profiles/r2_bench_kernel_stats.csv
+    python scripts/compose_counters.py <tag> [round]   -> profiles/<round>_room_counters.json, _spheres_counters.json,
+                                                          _bvh_counters.json, _bench_kernel_stats.csv   (round: r3)
 Counters are summed over the chip and over all kernels of the one rt_render call each profiled script makes."""
 import csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r3"
 root = f"gpurun_out/prof_{tag}"
 
 
@@ -47,8 +48,14 @@ def compose(prefix, workload, kernel, rays_pattern):
     if "SQ_THREAD_CYCLES_VALU" in c and "SQ_INSTS_VALU" in c:
         d["active_lanes_per_valu_instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64)"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"] / 64.0
         d["active_lanes_per_valu_instruction"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"] / 64.0
-    if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
-        d["valu_issue_busy (4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs))"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+    if "SQ_INSTS_VALU" in c:
+        # how hard the vector units are driven: wave-instructions per second over the whole chip, to be read against
+        # the rates microbench/valu_rates.hip measures (profiles/r2_valu_rates.txt: 835-965 G/s for full-rate
+        # instructions, 515-590 G/s for half-rate ones, ~680 G/s for this kernel's half-and-half mix)
+        d["valu_wave_instructions_per_s"] = c["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
+        d["salu_wave_instructions_per_s"] = c["SQ_INSTS_SALU"] / (kernel_ms * 1e-3)
+    if "SQ_INSTS_VALU_FMA_F64" in c:
+        d["fp64_share_of_valu_instructions"] = (c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"]) / c["SQ_INSTS_VALU"]
     if "TCC_HIT_sum" in c:
         d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
         d["l1_miss_rate (TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)"] = c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
@@ -63,14 +70,17 @@ def compose(prefix, workload, kernel, rays_pattern):
 
 
 os.makedirs("profiles", exist_ok=True)
-room = compose("room", "scripts/prof_room.py room 256: room 1920x1080, 256 spp, 8 bounces (bench.py's launch), one launch",
-               "rt::k_render<1,true,false,true> (+ full kernel passes, fold)", r"kernel ([0-9.]+) ms rays ([0-9]+)")
-json.dump(room, open("profiles/r2_room_counters.json", "w"), indent=1)
-bvh = compose("bvh", "scripts/prof_bvh.py 6 16: room + 1.18 M-triangle mesh (BASELINE config C4's scene), 1920x1080, 16 spp, 8 bounces, one launch",
-              "rt::k_render<2,true,false,true> (+ full kernel passes, fold)", r"kernel ([0-9.]+) ms rays ([0-9]+)")
-json.dump(bvh, open("profiles/r2_bvh_counters.json", "w"), indent=1)
+jobs = [("room", "scripts/prof_room.py room 256: room 1920x1080, 256 spp, 8 bounces (bench.py's launch), one launch",
+         "rt::k_render<1,true,true,true> (+ full kernel passes, fold)"),
+        ("spheres", "scripts/prof_room.py random_spheres_seed7 64: random_spheres (seed 7) 1920x1080, 64 spp, 8 bounces (BASELINE configs[1]), one launch",
+         "rt::k_render<0,true,true,true> (+ full kernel passes, fold)"),
+        ("bvh", "scripts/prof_bvh.py 6 16: room + 1.18 M-triangle mesh (BASELINE config C4's scene), 1920x1080, 16 spp, 8 bounces, one launch",
+         "rt::k_render<2,true,true,true> (+ full kernel passes, fold)")]
+for name, workload, kernel in jobs:
+    if not os.path.exists(f"{root}/{name}_sq_a.log"):
+        continue
+    out = compose(name, workload, kernel, r"kernel ([0-9.]+) ms rays ([0-9]+)")
+    json.dump(out, open(f"profiles/{rnd}_{name}_counters.json", "w"), indent=1)
+    print(name, {k.split(" (")[0]: (round(v, 4) if isinstance(v, float) else v) for k, v in out["derived"].items() if not isinstance(v, dict)})
 for f in glob.glob(f"{root}/stats/**/*kernel_stats.csv", recursive=True):
-    shutil.copy(f, "profiles/r2_bench_kernel_stats.csv")
-for name in ("room", "bvh"):
-    dd = json.load(open(f"profiles/r2_{name}_counters.json"))["derived"]
-    print(name, {k.split(" (")[0]: (round(v, 4) if isinstance(v, float) else v) for k, v in dd.items() if not isinstance(v, dict)})
+    shutil.copy(f, f"profiles/{rnd}_bench_kernel_stats.csv")
