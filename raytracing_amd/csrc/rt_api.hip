@@ -830,6 +830,12 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     HIP_TRY(c, c->box_rows.upload(box_rows)); HIP_TRY(c, c->box_face_id.upload(box_face_id)); HIP_TRY(c, c->box_face_rows.upload(box_face_rows));
     HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->slab_rows.upload(rows_slab)); HIP_TRY(c, c->leaf_rows.upload(rows_leaf)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
     HIP_TRY(c, c->tri_tight.upload(tri_tight));
+    const int n_sph_live = (int)sph_small.size();
+    if (n_sph_live > 1) {   // the sphere loop takes two rows per trip and reads one row ahead: dead rows (never candidates)
+        SphRow dead{}; dead.r2 = -INFINITY; dead.r = 0; dead.cn = 0; dead.qs = 0; dead.gprim = -2;
+        if (sph_small.size() % 2) sph_small.push_back(dead);
+        sph_small.push_back(dead);
+    }
     HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
     HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));
     HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
@@ -854,7 +860,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.slab_rows = c->slab_rows.as<SlabRow>(); S.n_quad_general = n_quad_general; S.slab_counts = slab_counts;
     S.box_rows = c->box_rows.as<BoxRow>(); S.box_face_id = c->box_face_id.as<int32_t>(); S.box_face_rows = c->box_face_rows.as<TriRow>();
     S.n_boxes = n_boxes; S.box_slack = up(1.01 * box_slack); S.box_tilt = up(1.01 * box_tilt + 1e-7);
-    S.sph_rows = c->sph_rows.as<SphRow>(); S.n_sph_rows = (int)sph_small.size();
+    S.sph_rows = c->sph_rows.as<SphRow>(); S.n_sph_rows = n_sph_live;
     S.big_sph = c->big_sph.as<int32_t>(); S.n_big_sph = (int)big.size();
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();
     S.sph_by_id = c->sph_by_id.as<SphRow>(); S.sph_obj = c->sph_obj.as<int32_t>();

@@ -1037,37 +1037,59 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
     return o;
 }
 
+// One small sphere of the table: the cheap discriminant test; a candidate gets a loose lower depth bound only
+// (band0 bounds the discriminant error for every sphere of the scene) - the winner's precise bounds are worked out
+// once, after the loops.
+template <class Sink>
+RT_DEV void sphere_row_test(const SphRow &P, const Ray &r, Sink &sink) {
+    float rox = r.ox - P.cx, roy = r.oy - P.cy, roz = r.oz - P.cz;
+    float b = fma_(roz, r.dz, fma_(roy, r.dy, rox * r.dx));
+    float cq = fma_(roz, roz, fma_(roy, roy, fma_(rox, rox, -P.r2)));
+    float disc = fma_(b, b, -(r.a * cq));
+    if (disc >= -r.band0) {
+        const float sh = sqrt_(disc + r.band0) * (1.0f + 4.0f * kU);
+        const float eb = kU * r.dlen * (6.0f * (abs_(rox) + abs_(roy) + abs_(roz)) + 2.0f * P.cn + r.o2);
+        const float nb = -b;
+        const float t1lo = (nb - sh - eb) * r.inv_a, t2hi = (nb + sh + eb) * r.inv_a, t2lo = (nb - eb) * r.inv_a;
+        bool valid; float tl;
+        if (P.gprim == r.origin) {           // only the far root, only when heading inwards
+            valid = b < eb;
+            tl = t2lo;
+        } else {
+            valid = t2hi > 0.0f;
+            tl = t1lo;
+        }
+        tl = max_(tl, 0.0f) * (1.0f - 8.0f * kU);
+        sink(valid ? tl : kInf, P.gprim);
+    }
+}
+
+// The small spheres, two per trip from two sets of scalar registers that take turns, each row's load issued a full
+// test ahead of its use (as slab_loop does, and for the same reasons; before, every sphere sat out its row's trip to
+// the scalar cache: a load, a wait, eleven vector instructions).  The host pads the table to an even count with a
+// dead row (r^2 = -inf: the discriminant is -inf) plus one to read ahead into.
 template <class Sink>
 RT_DEV void search_spheres(SceneRef S, const Ray &r, Sink &sink) {
-    const int n = S.n_sph_rows;
-    const SphRow *rows = S.sph_rows;
-#pragma unroll 2
-    for (int i = 0; i < n; ++i) {
-        const SphRow P = load_sph_row_uniform(rows, i);
-        float rox = r.ox - P.cx, roy = r.oy - P.cy, roz = r.oz - P.cz;
-        float b = fma_(roz, r.dz, fma_(roy, r.dy, rox * r.dx));
-        float cq = fma_(roz, roz, fma_(roy, roy, fma_(rox, rox, -P.r2)));
-        float disc = fma_(b, b, -(r.a * cq));
-        if (disc >= -r.band0) {
-            // Candidate.  Only a cheap, loose lower bound on the depth is formed here (band0 bounds the
-            // discriminant error for every sphere of the scene); the winner's precise bounds are
-            // worked out once, after the loops.
-            const float sh = sqrt_(disc + r.band0) * (1.0f + 4.0f * kU);
-            const float eb = kU * r.dlen * (6.0f * (abs_(rox) + abs_(roy) + abs_(roz)) + 2.0f * P.cn + r.o2);
-            const float nb = -b;
-            const float t1lo = (nb - sh - eb) * r.inv_a, t2hi = (nb + sh + eb) * r.inv_a, t2lo = (nb - eb) * r.inv_a;
-            bool valid; float tl;
-            if (P.gprim == r.origin) {           // only the far root, only when heading inwards
-                valid = b < eb;
-                tl = t2lo;
-            } else {
-                valid = t2hi > 0.0f;
-                tl = t1lo;
-            }
-            tl = max_(tl, 0.0f) * (1.0f - 8.0f * kU);
-            sink(valid ? tl : kInf, P.gprim);
-        }
-    }
+    const int n_live = S.n_sph_rows;
+    const SphRow *p = S.sph_rows;
+    if (n_live <= 0) return;
+    if (n_live == 1) { sphere_row_test(load_sph_row_uniform(p, 0), r, sink); return; }
+    int left = (n_live + 1) & ~1;
+    SphRow A = load_sph_row_uniform(p, 0);
+    do {
+        const SphRow *pb = p + 1;
+        asm volatile("" : "+s"(pb) : "s"(A.cx));
+        const SphRow B = load_sph_row_uniform(pb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        sphere_row_test(A, r, sink);
+        __builtin_amdgcn_sched_barrier(0);
+        p += 2;
+        asm volatile("" : "+s"(p) : "s"(B.cx));
+        A = load_sph_row_uniform(p, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        sphere_row_test(B, r, sink);
+        left -= 2;
+    } while (left > 0);
 }
 
 // The few huge spheres: double precision throughout.

@@ -295,7 +295,10 @@ RT_DEV KernargRenderArgs kernarg_render_args() {
     return (KernargRenderArgs)((cbyte)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DevScene) + 7) & ~(size_t)7));
 }
 
-constexpr int kJobBlock = 256;   // jobs a wave takes from the global counter at a time
+#ifndef RT_JOB_BLOCK
+#define RT_JOB_BLOCK 256
+#endif
+constexpr int kJobBlock = RT_JOB_BLOCK;   // jobs a wave takes from the global counter at a time
 constexpr int kWalkSlice = 4;   // wide nodes (four boxes each) a lane visits per trip of the render loop (hierarchy scenes)
 
 // STRICT: a float32 hit depth is accepted only under the closest-hit entry's error bound (9.5e-6
