@@ -243,9 +243,19 @@ int rt_accum_read(rt_ctx *ctx, float *host_w_h_3);      /* blocking copy of the 
  * rectangle.  Adds into `accum_dev` (device, float32 (W,H,3)); NULL = the context's own buffer.
  * Asynchronous on `stream`; rt_synchronize waits.  One call enqueues several kernels (see
  * RT_RENDER_NO_DEFER) that share context-owned scratch memory and counters: calls on one context go to
- * ONE stream, or are ordered by the caller (events) if they use several; contexts are independent. */
+ * ONE stream, or are ordered by the caller (events) if they use several; contexts are independent.
+ * Scratch: a call needs, in context-owned device memory that only ever grows, 33 bytes per JOB (a job is a pixel
+ * and a run of at least eight of its samples: at most rectangle x sample_count / 8 jobs, about 13 per pixel for
+ * calls of 256 samples at 1080p) plus 96 bytes per set-aside path for up to 1/64 of the call's paths (at least
+ * 4,096, at most 2^25 records), plus once per image size 48 bytes per pixel of camera rays: 1.8 GB for 1920 x 1080
+ * x 256 samples in one call, 0.5 GB for the same image in calls of 32 samples.  Several contexts on one GPU each
+ * hold their own; rt_release_scratch gives it back. */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, float *accum_dev, void *stream);
 int rt_synchronize(rt_ctx *ctx, void *stream);
+/* Frees the context's grow-only scratch (rt_render's job slots and set-aside lists, the wavefront form's queues, the
+ * staging of rt_intersect_batch and rt_postprocess); scene tables, accumulation buffer and camera-ray table stay.
+ * Waits for the device first; later calls allocate what they need again.  (No upstream counterpart.) */
+int rt_release_scratch(rt_ctx *ctx);
 
 /* Merge across GPUs.  Upstream has one process and one buffer (render_result.py:24-27: every tile
  * adds into the same arr); with one process per GPU, each rendering its share of the samples into

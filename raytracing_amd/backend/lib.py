@@ -24,7 +24,7 @@ RT_ERR_STOPPED = 5
 EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_intersect_batch",
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
            "rt_comm_available", "rt_comm_unique_id", "rt_comm_init", "rt_merge",
-           "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms", "rt_debug_scene_layout", "rt_debug_walk_fallbacks", "rt_debug_render_counters",
+           "rt_release_scratch", "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms", "rt_debug_scene_layout", "rt_debug_walk_fallbacks", "rt_debug_render_counters",
            "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_build_bvh_threads", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
 
@@ -91,6 +91,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.rt_merge.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.rt_request_stop.argtypes = [vp]
+    lib.rt_release_scratch.argtypes = [vp]
     lib.rt_clear_stop.argtypes = [vp]
     lib.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
     lib.rt_reset_stats.argtypes = [vp]
@@ -279,6 +280,10 @@ class HipBackend:
         self._check(self.lib.rt_debug_uniforms(self.handle, pixel, sample, seed, n_segments,
                                                out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
+
+    def release_scratch(self) -> None:
+        """Give the context's grow-only scratch memory back to the device (``rt_release_scratch``)."""
+        self._check(self.lib.rt_release_scratch(self.handle))
 
     def render_counters(self) -> dict:
         """What the last ``render`` call set aside (tests and tuning; synchronises).  ``jobs`` and

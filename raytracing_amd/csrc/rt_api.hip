@@ -111,7 +111,7 @@ struct rt_ctx {
     // the linear tables) and what it was built for: a later scene that differs only in vertex positions can be
     // refitted over it (RT_SCENE_REFIT)
     std::vector<rt_bvh_node> topo_nodes; std::vector<int32_t> topo_order, topo_mesh_begin; std::vector<char> topo_linear;
-    int32_t topo_leaf = 0; uint32_t topo_flags = 0;
+    int32_t topo_leaf = 0; uint32_t topo_flags = 0; double topo_area = 0;   // topo_area: summed box areas of that hierarchy when it was built
     bool last_refit = false;
     DevBuf isect_in, isect_out;          // rt_intersect_batch staging, grow-only (one call in flight per context)
     std::vector<EventPair> timed;        // recorded around render launches, not yet read
@@ -342,7 +342,12 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             bvh_nodes = c->topo_nodes; bvh_order = c->topo_order; linear_tri = c->topo_linear;
             bvh::refit(bvh_nodes, bvh_order, d->tri_verts);
             refitted = true;
-        } else {
+            // A topology built for other positions gets worse to walk the further the vertices move (boxes of
+            // neighbours overlap more and more): its quality is the sum of the boxes' areas, which is what the
+            // builder minimises.  Beyond 1.5 times the sum the hierarchy had when it was built, it is built anew.
+            if (bvh::area_sum(bvh_nodes) > 1.5 * c->topo_area) { refitted = false; bvh_nodes.clear(); bvh_order.clear(); linear_tri.clear(); }
+        }
+        if (use_bvh && bvh_nodes.empty() && d->n_bvh_nodes <= 0) {
             // Triangles that span a sizeable part of the scene (walls, floors) would sit in leaves near
             // the root whose boxes nearly every ray enters, and each test there costs four divergent
             // 16-byte loads per lane; the linear table tests them from scalar registers instead.  Up
@@ -382,6 +387,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             c->topo_nodes = bvh_nodes; c->topo_order = bvh_order; c->topo_linear = linear_tri;
             c->topo_mesh_begin.assign(d->mesh_tri_begin, d->mesh_tri_begin + d->n_meshes + 1);
             c->topo_leaf = d->bvh_leaf_size; c->topo_flags = d->flags & RT_SCENE_NO_LINEAR_SPLIT;
+            c->topo_area = bvh::area_sum(bvh_nodes);
         }
     }
     c->last_refit = refitted;
@@ -1352,6 +1358,19 @@ int rt_merge(rt_ctx *c, float *accum_dev, int32_t width, int32_t height, void *s
     HIP_TRY(c, hipSetDevice(c->device));
     const ncclResult_t e = rccl().all_reduce(buf, buf, (size_t)width * height * 3, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream);
     if (e != ncclSuccess) return fail(c, RT_ERR_HIP, "ncclAllReduce failed: %s", rccl_error(e));
+    return RT_OK;
+}
+
+// Hands the context's grow-only scratch back to the device (see the header): the render's job slots and set-aside
+// lists, the wavefront form's queues, the closest-hit entry's staging.  Tables of the scene, the accumulation buffer
+// and the camera-ray table stay.  Synchronises the device first; the next call that needs scratch allocates it again.
+int rt_release_scratch(rt_ctx *c) {
+    if (!c) return RT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    for (DevBuf *b : {&c->partial, &c->aside, &c->aside_head, &c->dirty, &c->dirty_list, &c->wf_rays[0], &c->wf_rays[1], &c->wf_paths,
+                      &c->wf_hits, &c->wf_radiance, &c->wf_partials, &c->wf_settle, &c->isect_in, &c->isect_out, &c->post_partials})
+        b->release();
     return RT_OK;
 }
 

@@ -309,6 +309,16 @@ inline void refit(std::vector<rt_bvh_node> &nodes, const std::vector<int32_t> &o
     }
 }
 
+// Sum of the half-areas of all boxes: the builder's cost measure, used to tell when a refitted topology has gone stale.
+inline double area_sum(const std::vector<rt_bvh_node> &nodes) {
+    double sum = 0;
+    for (const rt_bvh_node &nd : nodes) {
+        const double dx = (double)nd.hi[0] - nd.lo[0], dy = (double)nd.hi[1] - nd.lo[1], dz = (double)nd.hi[2] - nd.lo[2];
+        if (dx >= 0 && dy >= 0 && dz >= 0 && std::isfinite(dx + dy + dz)) sum += dx * dy + dy * dz + dz * dx;
+    }
+    return sum;
+}
+
 inline void rethread(const std::vector<rt_bvh_node> &src, int octant, std::vector<rt_bvh_node> &dst) {
     const int32_t n = (int32_t)src.size();
     dst.clear(); dst.reserve(n);

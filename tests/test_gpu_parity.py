@@ -1217,6 +1217,27 @@ def test_pixels_on_the_cube_edges_at_the_headline_resolution(backend):
     assert differ < 0.03 * len(xys)
 
 
+def test_release_scratch(backend):
+    """rt_release_scratch hands the render's grow-only scratch back to the device (several hundred MB after a 1080p
+    call); the next call allocates again and renders the same image bit for bit."""
+    import torch
+
+    _set(backend, "room")
+    W, H = 1920, 1080
+    backend.resize(W, H)
+    backend.render(W, H, 0, 16, 8, 5)
+    backend.synchronize()
+    first = backend.read()
+    held = torch.cuda.mem_get_info(0)[0]
+    backend.release_scratch()
+    freed = torch.cuda.mem_get_info(0)[0] - held
+    assert freed > 100 << 20, f"only {freed} bytes came back"
+    backend.clear()
+    backend.render(W, H, 0, 16, 8, 5)
+    backend.synchronize()
+    assert np.array_equal(backend.read(), first)
+
+
 def test_library_merge_one_rank(backend):
     """rt_comm_unique_id / rt_comm_init / rt_merge with a real RCCL communicator of ONE rank (all a
     one-GPU box can hold: RCCL refuses two ranks on one device): the all-reduce over one rank leaves
