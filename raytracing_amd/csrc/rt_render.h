@@ -142,9 +142,8 @@ __global__ __launch_bounds__(256) void k_raygen(const DevScene S_arg, int W, int
 // aperture offset and the re-aimed direction are worked out here from this path's two draws, in
 // double precision with a Newton reciprocal square root (~1e-16 of upstream's doubles), and the
 // float32 rounding of that ray is THE ray (no residue: the jitter decorrelates edge cases anyway).
-RT_DEV void camera_ray(SceneRef S, const float *ray_dir, const float *ray_res, uint32_t pixel, uint32_t key0,
+RT_DEV void camera_ray(SceneRef S, const f4 q, const float *ray_res, uint32_t pixel, uint32_t key0,
                        uint32_t key1, float &ox, float &oy, float &oz, float &dx, float &dy, float &dz) {
-    const f4 q = *(const f4 *)(ray_dir + 4 * (size_t)pixel);
     dx = q.x; dy = q.y; dz = q.z;
     ox = S.cam_pos[0]; oy = S.cam_pos[1]; oz = S.cam_pos[2];
     if (S.dof_on) {
@@ -223,12 +222,17 @@ struct Path {
     uint32_t pixel;                 // x * H + y: Philox key and row of the camera-ray table
 };
 
-RT_DEV void path_begin(SceneRef S, const float *ray_dir, const float *ray_res, Path &p, uint32_t pixel,
+// `q`: the pixel's entry of the camera-ray table (float32 direction)
+RT_DEV void path_begin(SceneRef S, const f4 q, const float *ray_res, Path &p, uint32_t pixel,
                        uint32_t sample, uint32_t seed_lo, uint32_t seed_hi) {
     p.key0 = pixel ^ seed_lo; p.key1 = sample ^ seed_hi;
-    camera_ray(S, ray_dir, ray_res, pixel, p.key0, p.key1, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz);
+    camera_ray(S, q, ray_res, pixel, p.key0, p.key1, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz);
     p.pixel = pixel;
     p.tr = p.tg = p.tb = 1.0f; p.depth = 0; p.inside = false; p.origin = -1; p.tag = 0u; p.own_ratio = kInf;
+}
+RT_DEV void path_begin(SceneRef S, const float *ray_dir, const float *ray_res, Path &p, uint32_t pixel,
+                       uint32_t sample, uint32_t seed_lo, uint32_t seed_hi) {
+    path_begin(S, *(const f4 *)(ray_dir + 4 * (size_t)pixel), ray_res, p, pixel, sample, seed_lo, seed_hi);
 }
 
 
@@ -296,8 +300,12 @@ RT_DEV KernargRenderArgs kernarg_render_args() {
 }
 
 #ifndef RT_JOB_BLOCK
-#define RT_JOB_BLOCK 256
+#define RT_JOB_BLOCK 64
 #endif
+// Jobs a wave takes from the global counter at a time.  When the counter runs out, a wave that has just taken a window
+// still holds that much work while its neighbours go idle: measured with windows of 256 / 128 / 64 / 32 jobs, 1.18 M
+// triangles 32 spp 30.2 / 28.6 / 28.6 / 28.7 ms, spheres scene 32 spp 9.55 / 9.02 / 8.91 / 9.30 ms, room 64 spp 12.85 /
+// 12.75 / 12.80 / 13.04 ms.
 constexpr int kJobBlock = RT_JOB_BLOCK;   // jobs a wave takes from the global counter at a time
 constexpr int kWalkSlice = 4;   // wide nodes (four boxes each) a lane visits per trip of the render loop (hierarchy scenes)
 
@@ -341,6 +349,12 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
     uint32_t w_exact = 0, w_refine = 0;
     uint32_t l_rays = 0, l_sky = 0;   // this lane's own counts
     BvhCounters bc = bvh_counters();   // hierarchy only: per-lane test counts, reduced at the end
+    // Every sample of a job starts with the job's pixel's camera-ray table entry: fetched once per job into the
+    // lane's LDS slot, read from there at every path start (an LDS read instead of a trip to the vector cache:
+    // room -1 %).  Linear-table scenes with triangles only: the spheres kernel measures the same either way, and
+    // the hierarchy kernel's LDS is spoken for (4 KB more cost it a workgroup per CU: +11 %).
+    constexpr bool kJobRayLds = TRI == kTriBrute;
+    __shared__ f4 job_ray[kJobRayLds ? 256 : 1];
     // hierarchy only: a closest-hit query in progress (walked a slice per trip of the main loop)
     typename FirstPass<TRI>::type first;
     first.init(S);
@@ -430,6 +444,7 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
                 ar = ag = ab = 0.0;
                 job_rays0 = l_rays; job_sky0 = l_sky; job_last_rec = -1;
                 have_job = true; in_path = false;
+                if (kJobRayLds) job_ray[threadIdx.x] = *(const f4 *)(A.ray_dir + 4 * (size_t)p.pixel);
                 }
             }
             uint32_t want = (uint32_t)__builtin_popcountll(idle);
@@ -448,7 +463,9 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
         if (have_job) {
             // ---- 2. start the next sample of this lane's pixel --------------------------------
             if (!in_path) {
-                path_begin(S, A.ray_dir, A.ray_res, p, p.pixel, (uint32_t)s_cur, A.seed_lo, A.seed_hi);
+                // (path mode never comes here: a record is a path under way)
+                if (kJobRayLds) path_begin(S, job_ray[threadIdx.x], A.ray_res, p, p.pixel, (uint32_t)s_cur, A.seed_lo, A.seed_hi);
+                else path_begin(S, A.ray_dir, A.ray_res, p, p.pixel, (uint32_t)s_cur, A.seed_lo, A.seed_hi);
                 in_path = true;
             }
             PROF(kProfBegin);
