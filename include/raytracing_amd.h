@@ -189,6 +189,21 @@ int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_
  * depend on it. */
 int rt_build_bvh_threads(int32_t n_threads);
 
+/* The FOUR-WIDE form of a threaded hierarchy, as rt_set_scene makes it for the kernels (CPU only; tests and
+ * tooling; no upstream counterpart).  A node is 128 bytes = 32 words:
+ *   [0..23]  float: centre and half-extent of each child's box, per axis: cx[4] hx[4] cy[4] hy[4] cz[4] hz[4]
+ *            ([c - h, c + h] contains the child's box; an empty slot has h = -1e30);
+ *   [24..27] int32: a LEAF child's triangle range (first << 4 | count), -1 for an inner child;
+ *   [28,29]  per octant of ray directions (bit k = direction negative along axis k) one byte of four 2-bit slot
+ *            numbers, near to far: octant o is byte o & 3 of word 28 + (o >> 2);
+ *   [30]     int32: index of the first inner child; inner children follow one another in slot order;
+ *   [31]     bits 0-3: slots holding inner nodes, bits 4-7: slots holding anything.
+ * `nodes` must be a valid hierarchy in rt_build_bvh's layout.  Writes the node count to *n_wide_out, the stack
+ * entries the deepest walk can need to *stack_need_out and, when wide_out is non-NULL and wide_capacity suffices
+ * (n_nodes always does), the nodes. */
+int rt_collapse_bvh(int32_t n_nodes, const rt_bvh_node *nodes, void *wide_out, int32_t wide_capacity, int32_t *n_wide_out,
+                    int32_t *stack_need_out);
+
 /* Host-side Wavefront OBJ reader with the semantics of Mesh.load_from_obj_file
  * (src/mesh/mesh.py:211-251): one object per "o" record, first index of each a/b/c corner, face
  * indices rebased by the vertex count of earlier objects, fan triangulation.  CPU only.

@@ -80,3 +80,26 @@ def check_flat_bvh(nodes: np.ndarray, tri_index: np.ndarray, tri_verts: np.ndarr
             raise ValueError(f"node {i} unreachable")
         if not leaf[i]:
             stack.append((int(skip[i]), i))
+
+
+#: numpy view of the four-wide node the kernels walk (``rt_collapse_bvh`` in include/raytracing_amd.h)
+WIDE_DTYPE = np.dtype([("cx", np.float32, (4,)), ("hx", np.float32, (4,)), ("cy", np.float32, (4,)), ("hy", np.float32, (4,)),
+                       ("cz", np.float32, (4,)), ("hz", np.float32, (4,)), ("link", np.int32, (4,)), ("order", np.uint32, (2,)),
+                       ("first", np.int32), ("inner", np.uint32)])
+assert WIDE_DTYPE.itemsize == 128
+
+
+def collapse_flat_bvh(nodes: np.ndarray) -> tuple[np.ndarray, int]:
+    """(wide nodes, stack entries the deepest walk can need) for a hierarchy in ``build_flat_bvh``'s layout: the
+    four-wide form ``rt_set_scene`` makes for the kernels (CPU only)."""
+    from .lib import load_library
+
+    lib = load_library()
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    wide = np.zeros(max(len(nodes), 1), WIDE_DTYPE)
+    n_wide, need = C.c_int32(0), C.c_int32(0)
+    st = lib.rt_collapse_bvh(len(nodes), nodes.ctypes.data_as(C.c_void_p), wide.ctypes.data_as(C.c_void_p), len(wide),
+                             C.byref(n_wide), C.byref(need))
+    if st != 0:
+        raise RuntimeError(f"rt_collapse_bvh failed with status {st}")
+    return np.ascontiguousarray(wide[: n_wide.value]), int(need.value)

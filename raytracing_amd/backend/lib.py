@@ -25,7 +25,7 @@ EXPORTS = ["rt_abi_version", "rt_create", "rt_destroy", "rt_last_error", "rt_set
            "rt_accum_resize", "rt_accum_clear", "rt_accum_device_ptr", "rt_accum_read", "rt_render", "rt_synchronize",
            "rt_comm_available", "rt_comm_unique_id", "rt_comm_init", "rt_merge",
            "rt_release_scratch", "rt_request_stop", "rt_clear_stop", "rt_get_stats", "rt_reset_stats", "rt_debug_uniforms", "rt_debug_scene_layout", "rt_debug_walk_fallbacks", "rt_debug_render_counters",
-           "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_build_bvh_threads", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
+           "rt_debug_trace_paths", "rt_raytrace_batch", "rt_postprocess", "rt_postprocess_noalloc", "rt_build_bvh", "rt_collapse_bvh", "rt_build_bvh_threads", "rt_obj_open", "rt_obj_read", "rt_obj_close"]
 
 
 class RtRenderParams(C.Structure):
@@ -106,6 +106,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_postprocess.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.POINTER(RtPostprocessParams), vp, vp]
     lib.rt_postprocess_noalloc.argtypes = lib.rt_postprocess.argtypes
     lib.rt_build_bvh_threads.argtypes = [C.c_int32]
+    lib.rt_collapse_bvh.argtypes = [C.c_int32, vp, vp, C.c_int32, ip, ip]
     lib.rt_build_bvh.argtypes = [C.c_int32, dp, C.c_int32, vp, C.c_int32, ip, ip]
     lp = C.POINTER(C.c_int64)
     lib.rt_obj_open.argtypes = [C.c_char_p, C.POINTER(vp), ip, lp, lp]

@@ -285,6 +285,26 @@ int rt_build_bvh(int32_t n_tris, const double *tri_verts, int32_t leaf_size, rt_
     return RT_OK;
 }
 
+int rt_collapse_bvh(int32_t n_nodes, const rt_bvh_node *nodes, void *wide_out, int32_t wide_capacity, int32_t *n_wide_out,
+                    int32_t *stack_need_out) {
+    if (n_nodes <= 0 || !nodes || !n_wide_out || wide_capacity < 0) return RT_ERR_INVALID_ARG;
+    // (structure only: the links must point forward and nest, as rt_set_scene requires of a caller's hierarchy)
+    for (int32_t i = 0; i < n_nodes; ++i) {
+        const int32_t end = nodes[i].skip < 0 ? n_nodes : nodes[i].skip;
+        if (end <= i || end > n_nodes || (nodes[i].tri_begin_count < 0 && end < i + 3)) return RT_ERR_INVALID_ARG;
+    }
+    std::vector<rt_bvh_node> src(nodes, nodes + n_nodes);
+    std::vector<WideNode> wide;
+    int32_t need = 0;
+    if (!bvh::collapse_wide(src, wide, &need)) return RT_ERR_UNSUPPORTED;
+    *n_wide_out = (int32_t)wide.size();
+    if (stack_need_out) *stack_need_out = need;
+    if (!wide_out) return RT_OK;
+    if ((int64_t)wide.size() > wide_capacity) return RT_ERR_INVALID_ARG;
+    std::memcpy(wide_out, wide.data(), sizeof(WideNode) * wide.size());
+    return RT_OK;
+}
+
 int rt_build_bvh_threads(int32_t n_threads) {
     if (n_threads < 0) return RT_ERR_INVALID_ARG;
     g_build_threads.store(n_threads);

@@ -209,6 +209,71 @@ def test_native_bvh_builder_output_is_a_valid_hierarchy():
         check_flat_bvh(bad, order, np.where(np.isfinite(tv), tv, 0.0))
 
 
+def test_wide_hierarchy_is_the_same_hierarchy():
+    """rt_collapse_bvh (CPU): the four-wide form the kernels walk, checked by an independent walk in numpy - from the
+    root every wide node is reached exactly once through the first-child arithmetic, the leaf ranges are exactly
+    the two-child hierarchy's leaves, every child's [c - h, c + h] contains the boxes of the two-child nodes it
+    stands for, the per-octant orders are permutations that put nearer centres first, and the reported stack need
+    is what the deepest walk can push."""
+    from raytracing_amd.backend.bvh import build_flat_bvh, collapse_flat_bvh
+
+    base = h.packed_scene("room_horse")
+    for levels, leaf in ((0, 2), (2, 2), (3, 1), (3, 6)):
+        sc = base.with_subdivided_mesh(base.n_meshes - 1, levels)
+        nodes, order = build_flat_bvh(sc.tri_verts, leaf_size=leaf)
+        wide, need = collapse_flat_bvh(nodes)
+        leaves2 = sorted(int(t) for t in nodes["tri"][nodes["tri"] >= 0])
+        # the two-child boxes by leaf range, for the containment check of leaf children
+        box_of_leaf = {int(nd["tri"]): (nd["lo"].astype(np.float64), nd["hi"].astype(np.float64)) for nd in nodes if nd["tri"] >= 0}
+        seen = np.zeros(len(wide), np.int64)
+        got_leaves, deepest = [], 0
+        stack = [(0, 0, None)]   # (wide node, stack entries in use when the walk reaches it, box the parent holds for it)
+        while stack:
+            w, pending, held = stack.pop()
+            seen[w] += 1
+            nd = wide[w]
+            inner, used = int(nd["inner"]) & 15, (int(nd["inner"]) >> 4) & 15
+            assert inner & ~used == 0 and used in (1, 3, 7, 15), (w, inner, used)   # slots are filled from the front
+            c = np.stack([nd["cx"], nd["cy"], nd["cz"]], 1).astype(np.float64)
+            hh = np.stack([nd["hx"], nd["hy"], nd["hz"]], 1).astype(np.float64)
+            n_inner = bin(inner).count("1")
+            deepest = max(deepest, pending + n_inner)
+            lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+            for k in range(4):
+                if not (used >> k) & 1:
+                    assert np.all(hh[k] < 0)            # an empty slot can never be hit
+                    continue
+                lo, hi = c[k] - hh[k], c[k] + hh[k]
+                lo_all, hi_all = np.minimum(lo_all, lo), np.maximum(hi_all, hi)
+                if (inner >> k) & 1:
+                    child = int(nd["first"]) + bin(inner & ((1 << k) - 1)).count("1")
+                    stack.append((child, pending + n_inner - 1, (lo, hi)))
+                else:
+                    rng = int(nd["link"][k])
+                    got_leaves.append(rng)
+                    blo, bhi = box_of_leaf[rng]
+                    assert np.all(lo <= blo) and np.all(hi >= bhi), (w, k)
+            if held is not None:
+                # what the parent holds for this node contains everything this node holds for its children (to the
+                # rounding of the centres: a few units in the last place of the scene size)
+                slack = 4e-7 * max(1.0, np.abs(c[used.bit_length() - 1]).max())
+                assert np.all(held[0] <= lo_all + slack) and np.all(held[1] >= hi_all - slack), w
+            for oct_ in range(8):
+                byte = (int(nd["order"][oct_ >> 2]) >> (8 * (oct_ & 3))) & 0xFF
+                perm = [(byte >> (2 * j)) & 3 for j in range(4)]
+                assert sorted(perm) == [0, 1, 2, 3]
+                sign = np.array([-1.0 if (oct_ >> a) & 1 else 1.0 for a in range(3)])
+                keys = [float(np.dot(sign, c[k])) for k in perm if (used >> k) & 1]
+                assert keys == sorted(keys), (w, oct_, perm, keys)
+        assert np.all(seen == 1) and sorted(got_leaves) == leaves2
+        assert need == deepest and need >= 1
+    # one leaf only: the root holds it
+    tv = np.zeros((1, 9)); tv[0, 3] = tv[0, 7] = 1.0
+    nodes, order = build_flat_bvh(tv)
+    wide, need = collapse_flat_bvh(nodes)
+    assert len(wide) == 1 and int(wide[0]["inner"]) == 0x10 and need == 0
+
+
 def test_subdivision_keeps_the_surface():
     """Midpoint subdivision: 4x the faces per level, same total area, same bounding box."""
     base = h.packed_scene("room_horse")
