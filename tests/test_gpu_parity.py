@@ -167,16 +167,18 @@ def test_paths_against_upstream_and_oracle(backend, scene, img):
 
 
 @pytest.mark.parametrize("scene,img,bound_up,bound_ruled", [
-    ("room", "image_room_96x54_8spp_8b.npz", 3e-2, 3e-2),
-    ("random_spheres_seed7", "image_random_spheres_320x180_16spp_4b.npz", 2e-2, 1e-3)])
+    ("room", "image_room_96x54_8spp_8b.npz", 2e-2, 2e-2),
+    ("random_spheres_seed7", "image_random_spheres_320x180_16spp_4b.npz", 2e-2, 2e-4)])
 def test_golden_images(backend, scene, img, bound_up, bound_ruled):
     """BASELINE configs[0] (random_spheres 320x180, 16 spp, 4 bounces) and a small room render made
     by upstream under the injected sample sequence.  Stated bounds: relative RMSE (RMSE / mean) of
     the sum image <= bound_up against upstream, <= bound_ruled against the oracle under the
     kernels' ray-origin rule; >= 99.9 % (room: 99.5 %) of pixels within 1e-3 relative of the latter.
-    The room bound is set by ~20 of the 5184 pixels: at 96x54 and a 90 degree field of view the image
-    diagonals project exactly onto the cube's edges, and paths that keep grazing those edges resolve
-    them differently in float32; every other pixel agrees to ~1e-7."""
+    The room bound is set by 17 of the 5184 pixels (measured relative RMSE 1.2e-2, all of it theirs): at 96x54
+    and a 90 degree field of view the image diagonals project exactly onto the cube's edges; the camera
+    segments of those paths are resolved from upstream's own doubles, but paths that keep grazing the edges
+    after a bounce start from float32 positions and pick the other face; every other pixel agrees to ~1e-7.
+    random_spheres against the oracle under the origin rule: measured 3e-5 (11 of 57,600 pixels beyond 1e-3)."""
     sc = _set(backend, scene)
     z, meta = h.load_npz(img)
     W, H, spp, b = meta["W"], meta["H"], meta["spp"], meta["bounces"]
