@@ -359,10 +359,12 @@ int rt_debug_render_counters(rt_ctx *ctx, uint32_t *out4);
  * renderer.py:21-79), and records every segment.  xys = [n_paths][3] (x, y, sample index).  Outputs
  * are host arrays; per-segment arrays hold max_bounces + 1 entries per path: hit object / primitive
  * (-1 = miss), which code produced the hit (see rt_intersect_batch), depth, ray origin, direction.
- * render_flags: 0 or RT_RENDER_LOOSE_DEPTH, as rt_render takes it. */
+ * render_flags: 0 or RT_RENDER_LOOSE_DEPTH, as rt_render takes it.  seg_org_residue (optional): a ray that leaves a hit
+ * the double-precision code produced starts at that hit's double-precision position (renderer.py:73-76); seg_org holds
+ * its float32 rounding and seg_org_residue what that rounding dropped (zero for every other ray). */
 int rt_debug_trace_paths(rt_ctx *ctx, int32_t n_paths, const int32_t *xys, int32_t width, int32_t height,
                          int32_t max_bounces, uint64_t seed, uint32_t render_flags, float *rgb, int32_t *n_seg, int32_t *seg_obj,
-                         int32_t *seg_prim, int32_t *seg_how, float *seg_t, float *seg_org, float *seg_dir);
+                         int32_t *seg_prim, int32_t *seg_how, float *seg_t, float *seg_org, float *seg_dir, float *seg_org_residue);
 
 #ifdef __cplusplus
 }

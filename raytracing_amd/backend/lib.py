@@ -100,7 +100,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rt_debug_render_counters.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.rt_debug_walk_fallbacks.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.rt_debug_trace_paths.argtypes = [vp, C.c_int32, ip, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32,
-                                         fp, ip, ip, ip, ip, fp, fp, fp]
+                                         fp, ip, ip, ip, ip, fp, fp, fp, fp]
     lib.rt_raytrace_batch.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_uint64,
                                       C.c_uint32, C.c_uint32, fp]
     lib.rt_postprocess.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.POINTER(RtPostprocessParams), vp, vp]
@@ -329,17 +329,20 @@ class HipBackend:
         return out
 
     def trace_paths(self, xys, width: int, height: int, max_bounces: int, seed: int, strict_depth: bool = True) -> dict:
-        """Whole paths with per-segment records (diagnostics / parity tests)."""
+        """Whole paths with per-segment records (diagnostics / parity tests).  ``org`` is the origin each segment's
+        ray starts from as the exact code sees it, in double precision: the float32 origin (``org32``) plus, behind a hit
+        the double-precision code produced, the part of that hit's position float32 cannot hold."""
         xys = np.ascontiguousarray(xys, dtype=np.int32).reshape(-1, 3)
         n, cap = xys.shape[0], max_bounces + 1
         out = dict(rgb=np.empty((n, 3), np.float32), n_seg=np.empty(n, np.int32), obj=np.empty((n, cap), np.int32),
                    prim=np.empty((n, cap), np.int32), how=np.empty((n, cap), np.int32), t=np.empty((n, cap), np.float32),
-                   org=np.empty((n, cap, 3), np.float32), dir=np.empty((n, cap, 3), np.float32))
+                   org32=np.empty((n, cap, 3), np.float32), dir=np.empty((n, cap, 3), np.float32), org_res=np.empty((n, cap, 3), np.float32))
         ip, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
         self._check(self.lib.rt_debug_trace_paths(
             self.handle, n, xys.ctypes.data_as(ip), width, height, max_bounces, seed & 0xFFFFFFFFFFFFFFFF,
             0 if strict_depth else RT_RENDER_LOOSE_DEPTH,
             out["rgb"].ctypes.data_as(fp), out["n_seg"].ctypes.data_as(ip), out["obj"].ctypes.data_as(ip),
             out["prim"].ctypes.data_as(ip), out["how"].ctypes.data_as(ip), out["t"].ctypes.data_as(fp),
-            out["org"].ctypes.data_as(fp), out["dir"].ctypes.data_as(fp)))
+            out["org32"].ctypes.data_as(fp), out["dir"].ctypes.data_as(fp), out["org_res"].ctypes.data_as(fp)))
+        out["org"] = out["org32"].astype(np.float64) + out["org_res"].astype(np.float64)
         return out

@@ -1532,7 +1532,7 @@ extern "C" int rt_debug_scene_layout(rt_ctx *c, int32_t *out, int32_t n_out, flo
 // Whole paths, one per thread, with every segment recorded (parity tests; not a fast path).
 extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *xys, int32_t width, int32_t height,
                                     int32_t max_bounces, uint64_t seed, uint32_t render_flags, float *rgb, int32_t *n_seg, int32_t *seg_obj,
-                                    int32_t *seg_prim, int32_t *seg_how, float *seg_t, float *seg_org, float *seg_dir) {
+                                    int32_t *seg_prim, int32_t *seg_how, float *seg_t, float *seg_org, float *seg_dir, float *seg_org_residue) {
     if (!c) return RT_ERR_INVALID_ARG;
     if (n_paths <= 0 || !xys || !rgb || !n_seg || !seg_obj || !seg_prim || !seg_how || !seg_t || !seg_org || !seg_dir ||
         width <= 0 || height <= 0 || max_bounces < 0 || max_bounces > 62)
@@ -1541,11 +1541,12 @@ extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *x
     HIP_TRY(c, hipSetDevice(c->device));
     const int cap = max_bounces + 1;
     const size_t np = (size_t)n_paths, ns = np * cap;
-    DevBuf b_xys, b_rgb, b_n, b_obj, b_prim, b_how, b_t, b_org, b_dir;
+    DevBuf b_xys, b_rgb, b_n, b_obj, b_prim, b_how, b_t, b_org, b_dir, b_res;
     HIP_TRY(c, b_xys.ensure(np * 12)); HIP_TRY(c, hipMemcpy(b_xys.p, xys, np * 12, hipMemcpyHostToDevice));
     HIP_TRY(c, b_rgb.ensure(np * 12)); HIP_TRY(c, b_n.ensure(np * 4));
     HIP_TRY(c, b_obj.ensure(ns * 4)); HIP_TRY(c, b_prim.ensure(ns * 4)); HIP_TRY(c, b_how.ensure(ns * 4)); HIP_TRY(c, b_t.ensure(ns * 4));
     HIP_TRY(c, b_org.ensure(ns * 12)); HIP_TRY(c, b_dir.ensure(ns * 12));
+    if (seg_org_residue) { HIP_TRY(c, b_res.ensure(ns * 12)); HIP_TRY(c, hipMemset(b_res.p, 0, ns * 12)); }
     HIP_TRY(c, hipMemset(b_obj.p, 0xFF, ns * 4)); HIP_TRY(c, hipMemset(b_prim.p, 0xFF, ns * 4)); HIP_TRY(c, hipMemset(b_how.p, 0xFF, ns * 4));
     HIP_TRY(c, hipMemset(b_t.p, 0, ns * 4)); HIP_TRY(c, hipMemset(b_org.p, 0, ns * 12)); HIP_TRY(c, hipMemset(b_dir.p, 0, ns * 12));
     TraceArgs A{};
@@ -1555,7 +1556,7 @@ extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *x
     A.ray_dir = c->ray_dir.as<float>(); A.ray_res = c->ray_res.as<float>();
     A.xys = b_xys.as<int32_t>(); A.rgb = b_rgb.as<float>(); A.n_seg = b_n.as<int32_t>(); A.seg_obj = b_obj.as<int32_t>();
     A.seg_prim = b_prim.as<int32_t>(); A.seg_how = b_how.as<int32_t>(); A.seg_t = b_t.as<float>();
-    A.seg_org = b_org.as<float>(); A.seg_dir = b_dir.as<float>();
+    A.seg_org = b_org.as<float>(); A.seg_dir = b_dir.as<float>(); A.seg_org_res = seg_org_residue ? b_res.as<float>() : nullptr;
     const DevScene S = c->S;
     dispatch_variant(c->tri_mode, c->has_sph, [&](auto T, auto P) {
         if (!(render_flags & RT_RENDER_LOOSE_DEPTH))
@@ -1571,6 +1572,7 @@ extern "C" int rt_debug_trace_paths(rt_ctx *c, int32_t n_paths, const int32_t *x
     HIP_TRY(c, hipMemcpy(seg_obj, b_obj.p, ns * 4, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(seg_prim, b_prim.p, ns * 4, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(seg_how, b_how.p, ns * 4, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(seg_t, b_t.p, ns * 4, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(seg_org, b_org.p, ns * 12, hipMemcpyDeviceToHost)); HIP_TRY(c, hipMemcpy(seg_dir, b_dir.p, ns * 12, hipMemcpyDeviceToHost));
+    if (seg_org_residue) HIP_TRY(c, hipMemcpy(seg_org_residue, b_res.p, ns * 12, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -163,8 +163,10 @@ RT_DEV uint32_t origin_tag(SceneRef S, int32_t origin) {
 
 // `rounded` = the ray is the float32 rounding of a double-precision ray the exact code will use
 // (camera rays): every bound then also covers u per component of o and d.
+// `origin_rounded` = the ORIGIN alone is the float32 rounding of a double-precision position the exact code will
+// use (a bounce ray that leaves a hit the exact code produced: see RayResidue).
 RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy, float dz, int32_t origin,
-                    bool rounded, uint32_t tag, float own_ratio = kInf) {
+                    bool rounded, uint32_t tag, float own_ratio = kInf, bool origin_rounded = false) {
     Ray r;
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.a = fma_(dz, dz, fma_(dy, dy, dx * dx));
@@ -172,12 +174,12 @@ RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy
     r.dlen = sqrt_(r.a);
     r.o2 = sqrt_(fma_(oz, oz, fma_(oy, oy, ox * ox))) * (1.0f + 4.0f * kU);
     float Sr = r.o2 + S.scene_radius;
-    const float k = rounded ? 1.3f * kU : 1.01f * kU;
+    const float k = (rounded || origin_rounded) ? 1.3f * kU : 1.01f * kU;
     r.c4 = 4.0f * k * Sr;
     r.c7 = 7.0f * k * r.dlen;
     r.band0 = 72.0f * kU * r.a * Sr * Sr;
     r.rk = rounded ? 1.01f * kU : 0.0f;
-    r.rko = (rounded && (S.cam_res[0] != 0.0f || S.cam_res[1] != 0.0f || S.cam_res[2] != 0.0f)) ? 1.01f * kU * r.o2 : 0.0f;
+    r.rko = ((rounded && (S.cam_res[0] != 0.0f || S.cam_res[1] != 0.0f || S.cam_res[2] != 0.0f)) || origin_rounded) ? 1.01f * kU * r.o2 : 0.0f;
     r.origin = origin;
     r.own_idf = (float)(tag & kTagIdMask);
     r.own_sign = u2f(0x3F800000u | (tag & kTagSecond));
@@ -1171,6 +1173,8 @@ RT_DEV void search_few_spheres(SceneRef S, const Ray &r, Sink &sink, SpherePre &
 struct Hit {
     int32_t obj, prim, gprim;   // obj < 0: miss
     float t, nx, ny, nz, px, py, pz;
+    float rpx, rpy, rpz;        // what the float32 hit position lacks of the double-precision one when the exact code produced the
+                                // hit (0 otherwise): the ray that leaves from here carries it as its origin's residue (RayResidue)
     uint32_t tag;               // TriAux::tag of the hit triangle (0 for a sphere): what the next ray's origin test needs
     // Upper bound on (distance of the float32 hit position from the true crossing point) / (distance of
     // that point from the nearest edge of the hit triangle); +inf when unknown (the double-precision
@@ -1193,9 +1197,16 @@ struct Hit {
 // resolves them, cracks between walls included.  `table` is null for every other ray.
 // `table` is the same for every lane (a kernel argument); only `on` and `pixel` are per-lane, and both already
 // live in the caller's state.
-struct RayResidue { const float *table; uint32_t pixel; bool on; };   // table: four doubles per pixel (x, y, z, unused)
+//
+// A BOUNCE ray that leaves a hit the exact code produced starts, upstream, at that hit's double-precision position
+// (renderer.py:73-76: the new ray starts exactly at hit_info.pos).  Such hits are the knife-edge ones - on an edge
+// between two walls, on a pair's diagonal - and the float32 rounding of the position, 5e-8 to one side or the other of
+// the neighbouring wall's plane, is what used to decide whether the next ray met that wall.  The ray therefore
+// carries (ox, oy, oz) = double-precision position - float32 position (as float32: 48 bits in all), the exact code
+// adds it back, and the float32 filter treats the origin as rounded (make_ray).
+struct RayResidue { const float *table; uint32_t pixel; bool on; float ox, oy, oz; bool o_on; };   // table: four doubles per pixel (x, y, z, unused)
 
-RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r.on = false; return r; }
+RT_DEV RayResidue no_residue() { RayResidue r; r.table = nullptr; r.pixel = 0; r.on = false; r.ox = r.oy = r.oz = 0.0f; r.o_on = false; return r; }
 
 // How the triangles of a scene are searched.
 enum { kTriNone = 0, kTriBrute = 1, kTriBvh = 2 };
@@ -1226,6 +1237,7 @@ RT_DEV Ray64 ray64(SceneRef S, const Ray &r, const RayResidue rr) {
     Ray64 x;
     x.o = d3((double)r.ox, (double)r.oy, (double)r.oz);
     x.d = d3((double)r.dx, (double)r.dy, (double)r.dz);
+    if (rr.o_on) x.o = d3(x.o.x + (double)rr.ox, x.o.y + (double)rr.oy, x.o.z + (double)rr.oz);
     if (rr.on) {
         const double *q = (const double *)rr.table + 4 * (size_t)rr.pixel;
         const double *cam = S.cold->cam64;
@@ -1279,6 +1291,7 @@ template <int TRI, bool HAS_SPH, bool STRICT, bool DEFER = false>
 RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typename FirstPass<TRI>::type &first,
                       BvhCounters bc, ExactHit *e64, const SpherePre *pre = nullptr) {
     Hit h; h.obj = -1; h.prim = -1; h.gprim = -1; h.t = kInf; h.nx = h.ny = h.nz = 0; h.px = h.py = h.pz = 0; h.how = 0; h.tag = 0u; h.own_ratio = kInf;
+    h.rpx = h.rpy = h.rpz = 0.0f;
     h.refined = false; h.bvh_nodes = bc.nodes; h.bvh_tris = bc.tris;
     const int route = ray_route<TRI>(r);
     int32_t gprim = -1; int root = 0; float t = kInf;
@@ -1428,6 +1441,7 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         if (h.how == 0) h.how = 1;
         h.t = (float)e.t; h.nx = (float)e.n.x; h.ny = (float)e.n.y; h.nz = (float)e.n.z;
         h.px = (float)e.pos.x; h.py = (float)e.pos.y; h.pz = (float)e.pos.z;
+        h.rpx = (float)(e.pos.x - (double)h.px); h.rpy = (float)(e.pos.y - (double)h.py); h.rpz = (float)(e.pos.z - (double)h.pz);
         return h;
     }
     h.t = t;

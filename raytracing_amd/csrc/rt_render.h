@@ -220,6 +220,7 @@ struct Path {
     float own_ratio;                // Hit::own_ratio of the hit the current ray leaves from
     bool inside;                    // Ray.inside (ray.py:10), toggled by refraction
     uint32_t pixel;                 // x * H + y: Philox key and row of the camera-ray table
+    float rox, roy, roz;            // residue of the current ray's origin (RayResidue): non-zero only behind a hit the exact code produced
 };
 
 // `q`: the pixel's entry of the camera-ray table (float32 direction)
@@ -229,6 +230,7 @@ RT_DEV void path_begin(SceneRef S, const f4 q, const float *ray_res, Path &p, ui
     camera_ray(S, q, ray_res, pixel, p.key0, p.key1, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz);
     p.pixel = pixel;
     p.tr = p.tg = p.tb = 1.0f; p.depth = 0; p.inside = false; p.origin = -1; p.tag = 0u; p.own_ratio = kInf;
+    p.rox = p.roy = p.roz = 0.0f;
 }
 RT_DEV void path_begin(SceneRef S, const float *ray_dir, const float *ray_res, Path &p, uint32_t pixel,
                        uint32_t sample, uint32_t seed_lo, uint32_t seed_hi) {
@@ -236,10 +238,13 @@ RT_DEV void path_begin(SceneRef S, const float *ray_dir, const float *ray_res, P
 }
 
 
+RT_DEV bool path_origin_rounded(const Path &p) { return p.rox != 0.0f || p.roy != 0.0f || p.roz != 0.0f; }
+
 RT_DEV RayResidue path_residue(SceneRef S, const float *ray_res, const Path &p) {
     // a pinhole camera ray is the rounding of a double-precision ray whose residue is in the table
     RayResidue rr;
     rr.table = ray_res; rr.pixel = p.pixel; rr.on = (p.depth == 0) && !S.dof_on;
+    rr.ox = p.rox; rr.oy = p.roy; rr.oz = p.roz; rr.o_on = path_origin_rounded(p);
     return rr;
 }
 
@@ -261,6 +266,7 @@ RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float
     PROF(kProfDraws);
     bool alive = shade_bounce(m, h, u, p.dx, p.dy, p.dz, p.inside, p.tr, p.tg, p.tb, er, eg, eb);
     p.ox = h.px; p.oy = h.py; p.oz = h.pz; p.origin = h.gprim; p.tag = h.tag; p.own_ratio = h.own_ratio;
+    p.rox = h.rpx; p.roy = h.rpy; p.roz = h.rpz;
     p.depth++;
     if (alive && p.depth > max_bounces) { alive = false; er = eg = eb = 0.0f; }   // renderer.py:29-30
     return alive;
@@ -271,7 +277,7 @@ RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float
 template <int TRI, bool HAS_SPH, bool STRICT = false, bool DEFER = false>
 RT_DEV bool path_step(SceneRef S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h,
                       uint32_t &sky_count) {
-    Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio);
+    Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio, path_origin_rounded(p));
     PROF(kProfRaySetup);
     h = closest_hit<TRI, HAS_SPH, STRICT, DEFER>(S, ray, nullptr, path_residue(S, ray_res, p));
     if (DEFER && h.how == kHowDeferred) { er = eg = eb = 0.0f; return false; }
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
     int32_t job_last_rec = -1;              // LEAN: the record of the path this lane's job set aside last (-1: none yet)
     Path p;
     p.ox = p.oy = p.oz = 0; p.dx = p.dy = 0; p.dz = 1; p.tr = p.tg = p.tb = 1; p.key0 = p.key1 = 0;
-    p.depth = 0; p.origin = -1; p.tag = 0u; p.own_ratio = kInf; p.inside = false; p.pixel = 0;
+    p.depth = 0; p.origin = -1; p.tag = 0u; p.own_ratio = kInf; p.inside = false; p.pixel = 0; p.rox = p.roy = p.roz = 0.0f;
     // Statistics are kept per WAVE in scalar registers (lane counts of ballots taken where the wave
     // is converged), not per lane: six vector registers less for the whole life of the kernel.
     uint32_t w_exact = 0, w_refine = 0;
@@ -414,6 +420,7 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
                     p.ox = rec.ox; p.oy = rec.oy; p.oz = rec.oz; p.dx = rec.dx; p.dy = rec.dy; p.dz = rec.dz;
                     p.tr = rec.tr; p.tg = rec.tg; p.tb = rec.tb; p.depth = (int32_t)rec.depth; p.origin = rec.origin;
                     p.tag = rec.tag; p.own_ratio = rec.own_ratio; p.inside = rec.inside != 0u;
+                    p.rox = p.roy = p.roz = 0.0f;   // (a record is written by the lean kernel, none of whose hits comes from the exact code)
                     ar = ag = ab = 0.0;
                     in_path = true; walking = false;
                     if constexpr (TRI == kTriBvh) {
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
             bool alive = true;
             if (TRI == kTriBvh) {
                 // resumable query: begin it if none is open, walk one slice, finish it when the walk is through
-                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio);
+                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio, path_origin_rounded(p));
                 const RayResidue rr = path_residue(S, A.ray_res, p);
                 PROF(kProfRaySetup);
                 PROF_LANES(kProfLanesStart, !walking);
@@ -691,6 +698,7 @@ struct TraceArgs {
     int32_t *seg_obj, *seg_prim, *seg_how;   // [n_paths][seg_cap]
     float *seg_t;                // [n_paths][seg_cap]
     float *seg_org, *seg_dir;    // [n_paths][seg_cap][3]
+    float *seg_org_res;          // [n_paths][seg_cap][3] or null: residue of the origin (RayResidue)
 };
 
 template <int TRI, bool HAS_SPH, bool STRICT>
@@ -708,6 +716,7 @@ __global__ __launch_bounds__(256) void k_trace_paths(const DevScene S_arg, const
         if (n < A.seg_cap) {
             A.seg_org[3 * k] = p.ox; A.seg_org[3 * k + 1] = p.oy; A.seg_org[3 * k + 2] = p.oz;
             A.seg_dir[3 * k] = p.dx; A.seg_dir[3 * k + 1] = p.dy; A.seg_dir[3 * k + 2] = p.dz;
+            if (A.seg_org_res) { A.seg_org_res[3 * k] = p.rox; A.seg_org_res[3 * k + 1] = p.roy; A.seg_org_res[3 * k + 2] = p.roz; }
         }
         Hit h;
         uint32_t sky_unused = 0;
@@ -745,14 +754,16 @@ __global__ __launch_bounds__(256) void k_raytrace(const DevScene S_arg, const Ra
         p.key0 = p.pixel ^ A.seed_lo; p.key1 = A.sample ^ A.seed_hi;
         p.ox = (float)A.org[3 * i]; p.oy = (float)A.org[3 * i + 1]; p.oz = (float)A.org[3 * i + 2];
         p.dx = (float)A.dir[3 * i]; p.dy = (float)A.dir[3 * i + 1]; p.dz = (float)A.dir[3 * i + 2];
-        p.tr = p.tg = p.tb = 1.0f; p.depth = A.first_depth; p.origin = -1; p.tag = 0u; p.own_ratio = kInf;
+        p.tr = p.tg = p.tb = 1.0f; p.depth = A.first_depth; p.origin = -1; p.tag = 0u; p.own_ratio = kInf; p.rox = p.roy = p.roz = 0.0f;
         p.inside = A.inside ? A.inside[i] != 0 : false;
         float er = 0, eg = 0, eb = 0;
         paths = 1;
         if (p.depth <= A.max_bounces) {   // renderer.py:29-30
             for (;;) {
-                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, false, p.tag, p.own_ratio);
-                const Hit h = closest_hit<TRI, HAS_SPH, true>(S, ray, nullptr, no_residue());
+                const Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, false, p.tag, p.own_ratio, path_origin_rounded(p));
+                RayResidue rr = no_residue();
+                rr.ox = p.rox; rr.oy = p.roy; rr.oz = p.roz; rr.o_on = path_origin_rounded(p);
+                const Hit h = closest_hit<TRI, HAS_SPH, true>(S, ray, nullptr, rr);
                 rays++;
                 if (h.obj < 0) sky++; else shaded++;
                 uint32_t sky_unused = 0;

@@ -33,13 +33,14 @@
 namespace rt {
 
 struct WfRay { float ox, oy, oz; int32_t origin; float dx, dy, dz; uint32_t path; };   // 32 B
-struct WfPath { float tr, tg, tb; uint32_t inside; uint32_t pixel, sample; int32_t depth; uint32_t pad; };   // 32 B
-struct WfHit {   // 48 B
+struct WfPath { float tr, tg, tb; uint32_t inside; uint32_t pixel, sample; int32_t depth; uint32_t pad; float rox, roy, roz; uint32_t pad1; };   // 48 B; ro*: Path::rox ...
+struct WfHit {
     float nx, ny, nz; int32_t obj;
     float px, py, pz; int32_t gprim;
     uint32_t flags;   // bit 0: contenders settled in double precision, bit 1: winner re-evaluated in double precision
     uint32_t first[3];   // a query on the settle list: its first pass's result (PairBest::lo0, lo1, id0 as bits)
-};
+    float rpx, rpy, rpz; uint32_t pad;   // Hit::rpx ...
+};   // 64 B
 
 struct WfArgs {
     int32_t width, height, x0, y0, rect_w, rect_h;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void k_wf_generate(const DevScene S_arg, const
     Path q;
     path_begin(S, A.ray_dir, A.ray_res, q, pixel, sample, A.seed_lo, A.seed_hi);
     WfRay r; r.ox = q.ox; r.oy = q.oy; r.oz = q.oz; r.origin = -1; r.dx = q.dx; r.dy = q.dy; r.dz = q.dz; r.path = p;
-    WfPath s; s.tr = s.tg = s.tb = 1.0f; s.inside = 0; s.pixel = pixel; s.sample = sample; s.depth = 0; s.pad = 0;
+    WfPath s; s.tr = s.tg = s.tb = 1.0f; s.inside = 0; s.pixel = pixel; s.sample = sample; s.depth = 0; s.pad = 0; s.rox = s.roy = s.roz = 0.0f; s.pad1 = 0;
     A.rays_in[p] = r;
     A.paths[p] = s;
     if (p == 0) *A.count_in = A.n_paths;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256, 5) void k_wf_extend(const DevScene S_arg, cons
     bool have = false, walking = false;
     WfRay ray; ray.ox = ray.oy = ray.oz = 0; ray.dx = ray.dy = 0; ray.dz = 1; ray.origin = -1; ray.path = 0;
     uint32_t pixel = 0, slot = 0; int32_t depth = 0;
+    float rox = 0.0f, roy = 0.0f, roz = 0.0f;   // residue of the ray's origin (RayResidue)
     typename FirstPass<TRI>::type first;
     first.init(S);
     int walk_node = -1;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256, 5) void k_wf_extend(const DevScene S_arg, cons
                 slot = win_next + rk;
                 ray = A.rays_in[slot];
                 const WfPath s = A.paths[ray.path];
-                pixel = s.pixel; depth = s.depth;
+                pixel = s.pixel; depth = s.depth; rox = s.rox; roy = s.roy; roz = s.roz;
                 have = true; walking = false;
             }
             const uint32_t want = (uint32_t)__builtin_popcountll(idle);
@@ -131,9 +133,11 @@ __global__ __launch_bounds__(256, 5) void k_wf_extend(const DevScene S_arg, cons
         if (__ballot(have) == 0) break;
         bool to_settle = false;
         if (have) {
-            const Ray r = make_ray(S, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, ray.origin, depth == 0, origin_tag(S, ray.origin));
+            const bool o_on = rox != 0.0f || roy != 0.0f || roz != 0.0f;
+            const Ray r = make_ray(S, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, ray.origin, depth == 0, origin_tag(S, ray.origin), kInf, o_on);
             RayResidue rr;
             rr.table = A.ray_res; rr.pixel = pixel; rr.on = (depth == 0) && !S.dof_on;
+            rr.ox = rox; rr.oy = roy; rr.oz = roz; rr.o_on = o_on;
             if (!walking) {
                 walking = true;
                 walk_node = -1;
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(256, 5) void k_wf_extend(const DevScene S_arg, cons
                 w.px = h.px; w.py = h.py; w.pz = h.pz; w.gprim = h.gprim;
                 w.flags = h.refined ? 2u : 0u;
                 w.first[0] = f2u(first.lo0); w.first[1] = f2u(first.lo1); w.first[2] = (uint32_t)first.id0;
+                w.rpx = h.rpx; w.rpy = h.rpy; w.rpz = h.rpz; w.pad = 0;
                 A.hits[ray.path] = w;
                 to_settle = h.how == kHowDeferred;
                 have = false; walking = false;
@@ -189,9 +194,11 @@ __global__ __launch_bounds__(256) void k_wf_settle(const DevScene S_arg, const W
         const WfRay ray = A.rays_in[A.settle_list[i]];
         const WfPath s = A.paths[ray.path];
         WfHit w = A.hits[ray.path];
-        const Ray r = make_ray(S, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, ray.origin, s.depth == 0, origin_tag(S, ray.origin));
+        const bool o_on = s.rox != 0.0f || s.roy != 0.0f || s.roz != 0.0f;
+        const Ray r = make_ray(S, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, ray.origin, s.depth == 0, origin_tag(S, ray.origin), kInf, o_on);
         RayResidue rr;
         rr.table = A.ray_res; rr.pixel = s.pixel; rr.on = (s.depth == 0) && !S.dof_on;
+        rr.ox = s.rox; rr.oy = s.roy; rr.oz = s.roz; rr.o_on = o_on;
         typename FirstPass<TRI>::type first;
         first.init(S);
         first.lo0 = u2f(w.first[0]); first.lo1 = u2f(w.first[1]); first.id0 = (int32_t)w.first[2];
@@ -200,6 +207,7 @@ __global__ __launch_bounds__(256) void k_wf_settle(const DevScene S_arg, const W
         w.nx = h.nx; w.ny = h.ny; w.nz = h.nz; w.obj = h.obj;
         w.px = h.px; w.py = h.py; w.pz = h.pz; w.gprim = h.gprim;
         w.flags = (h.how == 2 ? 1u : 0u) | (h.refined ? 2u : 0u);
+        w.rpx = h.rpx; w.rpy = h.rpy; w.rpz = h.rpz;
         A.hits[ray.path] = w;
     }
     // (second walks are counted like the first: per-block sums, one plain update of the block's own row)
@@ -256,6 +264,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const DevScene S_arg, const Wf
         Hit h;
         h.obj = w.obj; h.prim = 0; h.gprim = w.gprim; h.t = 0; h.nx = w.nx; h.ny = w.ny; h.nz = w.nz;
         h.px = w.px; h.py = w.py; h.pz = w.pz; h.how = 0; h.refined = false; h.bvh_nodes = 0; h.bvh_tris = 0; h.tag = 0u; h.own_ratio = kInf;
+        h.rpx = w.rpx; h.rpy = w.rpy; h.rpz = w.rpz;
         float er, eg, eb;
         uint32_t sky_unused = 0;   // (this kernel counts from its own flags)
         alive = path_shade(S, p, A.max_bounces, h, er, eg, eb, sky_unused);
@@ -263,6 +272,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const DevScene S_arg, const Wf
         if (alive) {
             WfPath t = s;
             t.tr = p.tr; t.tg = p.tg; t.tb = p.tb; t.depth = p.depth; t.inside = p.inside ? 1u : 0u;
+            t.rox = p.rox; t.roy = p.roy; t.roz = p.roz;
             A.paths[ray.path] = t;
             next.ox = p.ox; next.oy = p.oy; next.oz = p.oz; next.origin = p.origin;
             next.dx = p.dx; next.dy = p.dy; next.dz = p.dz; next.path = ray.path;

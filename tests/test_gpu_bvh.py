@@ -387,9 +387,10 @@ def test_wavefront_form_against_oracle(backend, monkeypatch):
     of the 4,608-triangle mesh, rendered in three batches, against the oracle's brute-force render of the same
     rectangle (origin rule, same sample sequence).  Pixels agree to float32 rounding except where a path lands ON an
     edge between two walls: in this rectangle the mirror reflections off the sphere do, for four pixels, by the
-    scene's symmetry; the hit there is the oracle's hit, segment by segment (scripts/wf_diag.py), but the next ray
-    starts from a float32 position 5e-8 away from the oracle's and leaves the corner through the other wall.  The
-    single-kernel form differs from the oracle in exactly the same four pixels.  Bound: 5 of 896."""
+    scene's symmetry.  The hit there is the oracle's hit, segment by segment (scripts/wf_diag.py), and the next ray
+    starts from the double-precision position of that hit (float32 + residue, carried through the queues), which
+    brings three of the four into line; the fourth reaches the edge by a float32 reflection 1e-7 off the oracle's.
+    Bound: 2 of 896 (measured 1)."""
     base = h.packed_scene("room_horse")
     sc = base.with_subdivided_mesh(base.n_meshes - 1, 2)
     backend.set_scene(sc)
@@ -416,7 +417,7 @@ def test_wavefront_form_against_oracle(backend, monkeypatch):
     assert not img[~inside].any() and np.isfinite(img).all()
     off = (np.abs(img - ref).max(axis=2) > 1e-3 * (1.0 + ref.max(axis=2))) & inside
     print(f"\nwavefront rectangle {rect}: {int(off.sum())} of {int(inside.sum())} pixels differ; rays {st['rays']} (oracle {rays})")
-    assert off.sum() <= 5, f"{int(off.sum())} pixels differ from the oracle"
+    assert off.sum() <= 2, f"{int(off.sum())} pixels differ from the oracle"
     # (a path that picks the other face at an edge goes on differently: a few rays more or fewer)
     assert abs(st["rays"] - rays) <= max(16, 0.002 * rays) and st["bvh_node_tests"] > 0, (st["rays"], rays)
 

@@ -167,17 +167,20 @@ def test_paths_against_upstream_and_oracle(backend, scene, img):
 
 
 @pytest.mark.parametrize("scene,img,bound_up,bound_ruled", [
-    ("room", "image_room_96x54_8spp_8b.npz", 2e-2, 2e-2),
+    ("room", "image_room_96x54_8spp_8b.npz", 1.5e-2, 1.5e-2),
     ("random_spheres_seed7", "image_random_spheres_320x180_16spp_4b.npz", 2e-2, 2e-4)])
 def test_golden_images(backend, scene, img, bound_up, bound_ruled):
     """BASELINE configs[0] (random_spheres 320x180, 16 spp, 4 bounces) and a small room render made
     by upstream under the injected sample sequence.  Stated bounds: relative RMSE (RMSE / mean) of
     the sum image <= bound_up against upstream, <= bound_ruled against the oracle under the
-    kernels' ray-origin rule; >= 99.9 % (room: 99.5 %) of pixels within 1e-3 relative of the latter.
-    The room bound is set by 17 of the 5184 pixels (measured relative RMSE 1.2e-2, all of it theirs): at 96x54
-    and a 90 degree field of view the image diagonals project exactly onto the cube's edges; the camera
-    segments of those paths are resolved from upstream's own doubles, but paths that keep grazing the edges
-    after a bounce start from float32 positions and pick the other face; every other pixel agrees to ~1e-7.
+    kernels' ray-origin rule; >= 99.9 % (room: 99.8 %) of pixels within 1e-3 relative of the latter.
+    The room bound is set by 6 of the 5184 pixels (measured relative RMSE 1.06e-2, all of it theirs): at 96x54
+    and a 90 degree field of view the image diagonals project exactly onto the cube's edges.  The camera
+    segments of those paths are resolved from upstream's own doubles, and a ray that leaves a hit the
+    double-precision code produced starts from that hit's double-precision position; what is left are mirror
+    reflections of those camera rays off a face-on wall: an unambiguous float32 hit, a float32 reflection that
+    stays in the diagonal plane to 1e-7, and a crack between two walls 1e-6 wide at its end (17 pixels and 1.2e-2
+    before bounce rays carried their origin's residue).  Every other pixel agrees to ~1e-7.
     random_spheres against the oracle under the origin rule: measured 3e-5 (11 of 57,600 pixels beyond 1e-3)."""
     sc = _set(backend, scene)
     z, meta = h.load_npz(img)
@@ -193,10 +196,12 @@ def test_golden_images(backend, scene, img, bound_up, bound_ruled):
     with h.origin_rule():
         ruled, rays = h.oracle_render(sc, W, H, spp, b)
     rel = lambda a, r: float(np.sqrt(np.mean((a - r) ** 2)) / np.mean(r))
+    close = np.abs(got - ruled).max(axis=2) <= 1e-3 * np.maximum(1.0, ruled.max(axis=2))
+    print(f"\n{scene} {W}x{H}: rel. RMSE {rel(got, up):.3e} (upstream), {rel(got, ruled):.3e} (oracle, origin rule); "
+          f"{int((~close).sum())} of {close.size} pixels beyond 1e-3")
     assert rel(got, up) <= bound_up, rel(got, up)
     assert rel(got, ruled) <= bound_ruled, rel(got, ruled)
-    close = np.abs(got - ruled).max(axis=2) <= 1e-3 * np.maximum(1.0, ruled.max(axis=2))
-    assert close.mean() >= (0.995 if scene == "room" else 0.999), close.mean()
+    assert close.mean() >= (0.998 if scene == "room" else 0.999), close.mean()
     assert abs(st["rays"] - rays) <= 2e-3 * rays   # same number of Scene.intersect calls
 
 
@@ -207,10 +212,10 @@ def test_golden_image_off_the_cube_edges(backend):
     those are the ones test_golden_images has to make room for).  Stated bounds, against upstream
     itself and against the oracle under the kernels' ray-origin rule (the room has no huge sphere, so
     upstream shows no acne and the two are the same image):
-      * >= 99.8 % of the pixels within 1e-4 relative (measured: 7 of 5,700 beyond it), and over those
+      * >= 99.85 % of the pixels within 1e-4 relative (measured: 5 of 5,700 beyond it), and over those
         pixels a relative RMSE <= 1e-6 (float32 shading against float64);
-      * relative RMSE of the whole sum image <= 5e-3 (measured 2.3e-3, all of it from those 7 pixels).
-    The 7 are sky texels, not intersections: the kernel's float32 atan2 / asin are good to 1.3e-4 of a
+      * relative RMSE of the whole sum image <= 3e-3 (measured 1.5e-3, all of it from those 5 pixels).
+    The 5 are sky texels, not intersections: the kernel's float32 atan2 / asin are good to 1.3e-4 of a
     texel, so about 2.6e-4 of the environment lookups land in the neighbouring texel of the 1907 x
     1001 image - with 8 samples per pixel and 0.6 lookups per path that is 1.2e-3 of the pixels."""
     sc = _set(backend, "room")
@@ -227,8 +232,8 @@ def test_golden_image_off_the_cube_edges(backend):
     close = np.abs(got - up).max(axis=2) <= 1e-4 * np.maximum(1.0, up.max(axis=2))
     print(f"\nroom 100x57: rel. RMSE {rel(got, up):.3e} (upstream), {rel(got, ruled):.3e} (oracle, origin rule); "
           f"{int((~close).sum())} of {close.size} pixels beyond 1e-4")
-    assert rel(got, up) <= 5e-3 and rel(got, ruled) <= 5e-3
-    assert close.mean() >= 0.998, close.mean()
+    assert rel(got, up) <= 3e-3 and rel(got, ruled) <= 3e-3
+    assert close.mean() >= 0.9985, close.mean()
     assert rel(got[close], up[close]) <= 1e-6, rel(got[close], up[close])
 
 
@@ -1199,9 +1204,14 @@ def test_pixels_on_the_cube_edges_at_the_headline_resolution(backend):
     typed with a wobble of 1e-6 - meet or leave a crack.  Their paths against the oracle's, path by path:
       * camera segments: identical hits on every path (the kernel resolves a pinhole ray from upstream's own
         doubles: float32 direction + its rounding residue kept as doubles);
-      * later segments: a bounce ray starts at the float32 rounding of the hit position, a few 1e-8 from upstream's
-        double-precision origin, and on these paths that origin lies ON an edge: fewer than 3 % of the paths part
-        company with the oracle's (measured 1.8 %: 155 of 8,640), i.e. 1.5e-5 of the image's paths."""
+      * later segments: a ray that leaves a hit the double-precision code produced - every hit ON an edge is one -
+        starts from that hit's double-precision position (float32 + residue), as upstream's does
+        (renderer.py:73-76).  What still parts company with the oracle (measured 30 of 8,640 paths, 0.35 %; 155
+        before the residue was carried; bound 0.6 %) is one kind of path (scripts/edge_diag.py): the camera ray meets
+        a face-on wall well inside it - an unambiguous float32 hit, position and mirror direction good to 1e-7 -
+        and the reflection, still in the diagonal plane, ends in the 1e-6 crack between two walls, where 1e-7
+        decides between a wall and the sky.  Only double-precision shading from the camera on would settle those:
+        3e-6 of the headline image's paths."""
     sc = _set(backend, "room")
     W, H, b, spp = 1920, 1080, 8, 4
     px = [(x, x - 420) for x in range(W) if 0 <= x - 420 < H] + [(x, 1499 - x) for x in range(W) if 0 <= 1499 - x < H]
@@ -1216,7 +1226,7 @@ def test_pixels_on_the_cube_edges_at_the_headline_resolution(backend):
             differ += int(not np.allclose(tr["rgb"][i], want, rtol=2e-3, atol=2e-4))
     print(f"\n{len(xys)} paths through the cube's edges: {differ} differ from the oracle's ({differ / len(xys):.2e}), {camera_differ} at the camera segment")
     assert camera_differ == 0
-    assert differ < 0.03 * len(xys)
+    assert differ < 0.006 * len(xys)
 
 
 def test_release_scratch(backend):
