@@ -857,10 +857,10 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->slab_rows.upload(rows_slab)); HIP_TRY(c, c->leaf_rows.upload(rows_leaf)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
     HIP_TRY(c, c->tri_tight.upload(tri_tight));
     const int n_sph_live = (int)sph_small.size();
-    if (n_sph_live > 1) {   // the sphere loop takes two rows per trip and reads one row ahead: dead rows (never candidates)
+    if (n_sph_live > 1) {   // the sphere loop takes four rows per trip and reads two rows ahead: dead rows (never candidates)
         SphRow dead{}; dead.r2 = -INFINITY; dead.r = 0; dead.cn = 0; dead.qs = 0; dead.gprim = -2;
-        if (sph_small.size() % 2) sph_small.push_back(dead);
-        sph_small.push_back(dead);
+        while (sph_small.size() % 4) sph_small.push_back(dead);
+        sph_small.push_back(dead); sph_small.push_back(dead);
     }
     HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
     HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));

@@ -1042,55 +1042,59 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
 // One small sphere of the table: the cheap discriminant test; a candidate gets a loose lower depth bound only
 // (band0 bounds the discriminant error for every sphere of the scene) - the winner's precise bounds are worked out
 // once, after the loops.
+//
+// The test runs for the whole wave or not at all: the branch is taken on a ballot (a scalar compare and a scalar
+// branch; a divergent `if` costs a save, a branch and a restore of the execution mask per row), and the body has no
+// branches of its own - both cases of "is this the sphere the ray starts on" are worked out and selected.  Lanes whose
+// discriminant is below the band hand the sink +inf.
 template <class Sink>
 RT_DEV void sphere_row_test(const SphRow &P, const Ray &r, Sink &sink) {
     float rox = r.ox - P.cx, roy = r.oy - P.cy, roz = r.oz - P.cz;
     float b = fma_(roz, r.dz, fma_(roy, r.dy, rox * r.dx));
     float cq = fma_(roz, roz, fma_(roy, roy, fma_(rox, rox, -P.r2)));
     float disc = fma_(b, b, -(r.a * cq));
-    if (disc >= -r.band0) {
-        const float sh = sqrt_(disc + r.band0) * (1.0f + 4.0f * kU);
+    const bool near = disc >= -r.band0;
+    if (__ballot(near) != 0) {
+        const float sh = sqrt_(max_(disc + r.band0, 0.0f)) * (1.0f + 4.0f * kU);
         const float eb = kU * r.dlen * (6.0f * (abs_(rox) + abs_(roy) + abs_(roz)) + 2.0f * P.cn + r.o2);
         const float nb = -b;
         const float t1lo = (nb - sh - eb) * r.inv_a, t2hi = (nb + sh + eb) * r.inv_a, t2lo = (nb - eb) * r.inv_a;
-        bool valid; float tl;
-        if (P.gprim == r.origin) {           // only the far root, only when heading inwards
-            valid = b < eb;
-            tl = t2lo;
-        } else {
-            valid = t2hi > 0.0f;
-            tl = t1lo;
-        }
+        // the sphere the ray starts on: only the far root, only when heading inwards
+        const bool own = P.gprim == r.origin;
+        const float gate = own ? eb - b : t2hi;      // own: heading inwards (b < eb); else: the far root is ahead
+        const bool valid = near & (gate > 0.0f);     // (bitwise: no short-circuit branch)
+        float tl = own ? t2lo : t1lo;
         tl = max_(tl, 0.0f) * (1.0f - 8.0f * kU);
         sink(valid ? tl : kInf, P.gprim);
     }
 }
 
-// The small spheres, two per trip from two sets of scalar registers that take turns, each row's load issued a full
-// test ahead of its use (as slab_loop does, and for the same reasons; before, every sphere sat out its row's trip to
-// the scalar cache: a load, a wait, eleven vector instructions).  The host pads the table to an even count with a
-// dead row (r^2 = -inf: the discriminant is -inf) plus one to read ahead into.
+// The small spheres, four per trip from four sets of scalar registers, two rows loaded at a time a pair of tests
+// ahead of their use; the row pointer moves once per trip and the loads take their offsets as immediates (one pointer
+// update and one loop test per four rows).  The host pads the table to a multiple of four with dead rows (r^2 = -inf:
+// the discriminant is -inf) plus two to read ahead into.
 template <class Sink>
 RT_DEV void search_spheres(SceneRef S, const Ray &r, Sink &sink) {
     const int n_live = S.n_sph_rows;
     const SphRow *p = S.sph_rows;
     if (n_live <= 0) return;
     if (n_live == 1) { sphere_row_test(load_sph_row_uniform(p, 0), r, sink); return; }
-    int left = (n_live + 1) & ~1;
-    SphRow A = load_sph_row_uniform(p, 0);
+    int left = (n_live + 3) & ~3;
+    SphRow A = load_sph_row_uniform(p, 0), B = load_sph_row_uniform(p, 1);
     do {
-        const SphRow *pb = p + 1;
-        asm volatile("" : "+s"(pb) : "s"(A.cx));
-        const SphRow B = load_sph_row_uniform(pb, 0);
+        asm volatile("" : "+s"(p) : "s"(A.cx), "s"(B.cx));
+        const SphRow C = load_sph_row_uniform(p, 2), D = load_sph_row_uniform(p, 3);
         __builtin_amdgcn_sched_barrier(0);
         sphere_row_test(A, r, sink);
-        __builtin_amdgcn_sched_barrier(0);
-        p += 2;
-        asm volatile("" : "+s"(p) : "s"(B.cx));
-        A = load_sph_row_uniform(p, 0);
-        __builtin_amdgcn_sched_barrier(0);
         sphere_row_test(B, r, sink);
-        left -= 2;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+s"(p) : "s"(C.cx), "s"(D.cx));
+        A = load_sph_row_uniform(p, 4); B = load_sph_row_uniform(p, 5);
+        __builtin_amdgcn_sched_barrier(0);
+        sphere_row_test(C, r, sink);
+        sphere_row_test(D, r, sink);
+        p += 4;
+        left -= 4;
     } while (left > 0);
 }
 
