@@ -106,6 +106,16 @@ RT_DEV SphRow load_sph_row_uniform(const SphRow *rows, int i) {
     return P;
 }
 
+RT_DEV SphLoopRow load_sph_loop_row_uniform(const SphLoopRow *rows, int i) {
+    const_f4_ptr q = as_const_f4(rows) + 2 * (size_t)i;
+    f4 a = q[0], b = q[1];
+    SphLoopRow P;
+    P.cx = a.x; P.cy = a.y; P.cz = a.z; P.ks = a.w;
+    const float id_bits = b.x;
+    P.gprim = (int32_t)f2u(id_bits);
+    return P;
+}
+
 RT_DEV SlabRow load_slab_row_uniform(const SlabRow *rows, int i) {
     const_f4_ptr q = as_const_f4(rows) + 3 * (size_t)i;
     f4 a = q[0], b = q[1], c = q[2];
@@ -1039,29 +1049,56 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
     return o;
 }
 
-// One small sphere of the table: the cheap discriminant test; a candidate gets a loose lower depth bound only
-// (band0 bounds the discriminant error for every sphere of the scene) - the winner's precise bounds are worked out
-// once, after the loops.
+// One small sphere of the search loop's table: the cheap discriminant test; a candidate gets a loose lower depth bound
+// only - the winner's precise bounds are worked out once, after the loops (sphere_bounds).
 //
-// The test runs for the whole wave or not at all: the branch is taken on a ballot (a scalar compare and a scalar
-// branch; a divergent `if` costs a save, a branch and a restore of the execution mask per row), and the body has no
+// The discriminant b^2 - a cq (b = (o - c).d, cq = |o - c|^2 - r^2) is evaluated in its expanded form, which leaves
+// the row nine vector instructions where the differences o - c cost twelve:
+//     disc = w^2 + c.q - (a ks + m),   w = c.d,   q = 2 (a o - (o.d) d),   m = |o x d|^2 = a |o|^2 - (o.d)^2,
+// ks = |c|^2 - r^2 from the row, q and m once per ray (SphRay).  What it costs is cancellation at the scale of the scene
+// instead of the scale of |o - c|, and the band the test works with (Ray::band0 = 72 u a S^2, S = |o| + scene radius)
+// already is of that scale.  Error against the exact discriminant of the float32 ray and the double-precision
+// sphere, in units of u a (u = 2^-24; O = |o|, C = |c|, r the radius, C + r <= scene radius):
+//   * a: three roundings, 3 u a; o.d: 3 u O |d|;
+//   * o x d: two roundings per component, 3.5 u O |d| in norm; m: 2 |o x d| times that plus three roundings: 10.1 O^2;
+//   * q: per component 4 u a |o_i| (a and its product) + 3 u O |d| |d_i| + u a O (the multiply-add), doubled: 17.6 u a O
+//     in norm, and |q| <= 2 a O;
+//   * w: three roundings and the centre's own rounding, 4 u C |d|; w^2: 8 C^2;
+//   * c.q: 17.6 C O + 2 C O (the centre's rounding);  a ks: 4 (C^2 + r^2) (a, the product, the rounding of ks);
+//   * five multiply-adds whose partial sums stay below 2 a S^2: 10 S^2.
+// Sum: 12 C^2 + 4 r^2 + 19.6 C O + 10.1 O^2 + 10 S^2 <= 22 S^2, a third of the band.  The same band bounds sqrt(disc)
+// from above in the body, and b = o.d - w is off by at most u |d| (3 O + 4 C + O + C) <= 5 u |d| S.  A ray that is the
+// rounding of a double-precision one (camera rays, origins with a residue) moves the discriminant by another
+// 6 u a S^2 and b by 2 u |d| S: 28 of the band's 72, and SphRay::eb = 8 u |d| S.
+//
+// The test runs for the whole wave or not at all: the branch is taken on a ballot (a scalar branch on the compare's own
+// mask; a divergent `if` costs a save, a branch and a restore of the execution mask per row), and the body has no
 // branches of its own - both cases of "is this the sphere the ray starts on" are worked out and selected.  Lanes whose
 // discriminant is below the band hand the sink +inf.
+struct SphRay { float qx, qy, qz, m, od, eb; };
+
+RT_DEV SphRay sph_ray(SceneRef S, const Ray &r) {
+    SphRay q;
+    q.od = fma_(r.oz, r.dz, fma_(r.oy, r.dy, r.ox * r.dx));
+    const float kx = fma_(r.oy, r.dz, -(r.oz * r.dy)), ky = fma_(r.oz, r.dx, -(r.ox * r.dz)), kz = fma_(r.ox, r.dy, -(r.oy * r.dx));
+    q.m = fma_(kz, kz, fma_(ky, ky, kx * kx));
+    q.qx = 2.0f * fma_(-q.od, r.dx, r.a * r.ox); q.qy = 2.0f * fma_(-q.od, r.dy, r.a * r.oy); q.qz = 2.0f * fma_(-q.od, r.dz, r.a * r.oz);
+    q.eb = 8.0f * kU * r.dlen * (r.o2 + S.scene_radius);
+    return q;
+}
+
 template <class Sink>
-RT_DEV void sphere_row_test(const SphRow &P, const Ray &r, Sink &sink) {
-    float rox = r.ox - P.cx, roy = r.oy - P.cy, roz = r.oz - P.cz;
-    float b = fma_(roz, r.dz, fma_(roy, r.dy, rox * r.dx));
-    float cq = fma_(roz, roz, fma_(roy, roy, fma_(rox, rox, -P.r2)));
-    float disc = fma_(b, b, -(r.a * cq));
+RT_DEV void sphere_row_test(const SphLoopRow &P, const SphRay &q, const Ray &r, Sink &sink) {
+    const float w = fma_(P.cz, r.dz, fma_(P.cy, r.dy, P.cx * r.dx));
+    const float disc = fma_(w, w, fma_(P.cz, q.qz, fma_(P.cy, q.qy, fma_(P.cx, q.qx, fma_(-r.a, P.ks, -q.m)))));
     const bool near = disc >= -r.band0;
     if (__ballot(near) != 0) {
         const float sh = sqrt_(max_(disc + r.band0, 0.0f)) * (1.0f + 4.0f * kU);
-        const float eb = kU * r.dlen * (6.0f * (abs_(rox) + abs_(roy) + abs_(roz)) + 2.0f * P.cn + r.o2);
-        const float nb = -b;
-        const float t1lo = (nb - sh - eb) * r.inv_a, t2hi = (nb + sh + eb) * r.inv_a, t2lo = (nb - eb) * r.inv_a;
-        // the sphere the ray starts on: only the far root, only when heading inwards
+        const float nb = w - q.od;                   // -b
+        const float t1lo = (nb - sh - q.eb) * r.inv_a, t2lo = (nb - q.eb) * r.inv_a;
+        // the sphere the ray starts on: only the far root, only when heading inwards (b < eb); any other: a root ahead
         const bool own = P.gprim == r.origin;
-        const float gate = own ? eb - b : t2hi;      // own: heading inwards (b < eb); else: the far root is ahead
+        const float gate = own ? q.eb + nb : nb + sh + q.eb;
         const bool valid = near & (gate > 0.0f);     // (bitwise: no short-circuit branch)
         float tl = own ? t2lo : t1lo;
         tl = max_(tl, 0.0f) * (1.0f - 8.0f * kU);
@@ -1071,28 +1108,29 @@ RT_DEV void sphere_row_test(const SphRow &P, const Ray &r, Sink &sink) {
 
 // The small spheres, four per trip from four sets of scalar registers, two rows loaded at a time a pair of tests
 // ahead of their use; the row pointer moves once per trip and the loads take their offsets as immediates (one pointer
-// update and one loop test per four rows).  The host pads the table to a multiple of four with dead rows (r^2 = -inf:
+// update and one loop test per four rows).  The host pads the table to a multiple of four with dead rows (ks = +inf:
 // the discriminant is -inf) plus two to read ahead into.
 template <class Sink>
 RT_DEV void search_spheres(SceneRef S, const Ray &r, Sink &sink) {
     const int n_live = S.n_sph_rows;
-    const SphRow *p = S.sph_rows;
+    const SphLoopRow *p = S.sph_loop;
     if (n_live <= 0) return;
-    if (n_live == 1) { sphere_row_test(load_sph_row_uniform(p, 0), r, sink); return; }
+    const SphRay q = sph_ray(S, r);
+    if (n_live == 1) { sphere_row_test(load_sph_loop_row_uniform(p, 0), q, r, sink); return; }
     int left = (n_live + 3) & ~3;
-    SphRow A = load_sph_row_uniform(p, 0), B = load_sph_row_uniform(p, 1);
+    SphLoopRow A = load_sph_loop_row_uniform(p, 0), B = load_sph_loop_row_uniform(p, 1);
     do {
         asm volatile("" : "+s"(p) : "s"(A.cx), "s"(B.cx));
-        const SphRow C = load_sph_row_uniform(p, 2), D = load_sph_row_uniform(p, 3);
+        const SphLoopRow C = load_sph_loop_row_uniform(p, 2), D = load_sph_loop_row_uniform(p, 3);
         __builtin_amdgcn_sched_barrier(0);
-        sphere_row_test(A, r, sink);
-        sphere_row_test(B, r, sink);
+        sphere_row_test(A, q, r, sink);
+        sphere_row_test(B, q, r, sink);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" : "+s"(p) : "s"(C.cx), "s"(D.cx));
-        A = load_sph_row_uniform(p, 4); B = load_sph_row_uniform(p, 5);
+        A = load_sph_loop_row_uniform(p, 4); B = load_sph_loop_row_uniform(p, 5);
         __builtin_amdgcn_sched_barrier(0);
-        sphere_row_test(C, r, sink);
-        sphere_row_test(D, r, sink);
+        sphere_row_test(C, q, r, sink);
+        sphere_row_test(D, q, r, sink);
         p += 4;
         left -= 4;
     } while (left > 0);

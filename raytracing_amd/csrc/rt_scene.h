@@ -86,6 +86,14 @@ struct SphRow {
     int32_t gprim;   // = sphere index
 };
 
+// The same sphere as the search loop reads it (search_spheres): the discriminant in its expanded form needs the centre
+// and ks = |c|^2 - r^2 (from the double-precision centre and radius, rounded once).  8 dwords, dead rows: ks = +inf.
+struct SphLoopRow {
+    float cx, cy, cz, ks;
+    int32_t gprim;
+    float pad[3];
+};
+
 // Ray-origin tag (TriAux::tag, carried from a hit to the ray that leaves it):
 //   bits 0-12   id + 1 of the first triangle of the origin's parallelogram row (0: the origin is in no such row)
 //   bits 14-23  1 + 8 * box + code when that row is a face of a box (0: it is not)
@@ -192,6 +200,7 @@ struct DevScene {
     // Per plane, what the float32 row's rounding and the order of its multiply-adds can cost: four floats (ax, ay, az, ak)
     // per triangle (by triangle id), then per parallelogram row (by row index).  See judge_tri.
     const float *tri_tight;
+    const SphLoopRow *sph_loop;                       // the small spheres again, in sph_rows' order, as the search loop reads them
 };
 static_assert(offsetof(DevScene, tri_aux) == 64 && offsetof(DevScene, cam_pos) == 128, "DevScene: the two hot runs are 16 dwords each");
 
