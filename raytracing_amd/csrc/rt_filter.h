@@ -1052,50 +1052,56 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
 // One small sphere of the search loop's table: the cheap discriminant test; a candidate gets a loose lower depth bound
 // only - the winner's precise bounds are worked out once, after the loops (sphere_bounds).
 //
-// The discriminant b^2 - a cq (b = (o - c).d, cq = |o - c|^2 - r^2) is evaluated in its expanded form, which leaves
-// the row nine vector instructions where the differences o - c cost twelve:
-//     disc = w^2 + c.q - (a ks + m),   w = c.d,   q = 2 (a o - (o.d) d),   m = |o x d|^2 = a |o|^2 - (o.d)^2,
-// ks = |c|^2 - r^2 from the row, q and m once per ray (SphRay).  What it costs is cancellation at the scale of the scene
-// instead of the scale of |o - c|, and the band the test works with (Ray::band0 = 72 u a S^2, S = |o| + scene radius)
-// already is of that scale.  Error against the exact discriminant of the float32 ray and the double-precision
-// sphere, in units of u a (u = 2^-24; O = |o|, C = |c|, r the radius, C + r <= scene radius):
-//   * a: three roundings, 3 u a; o.d: 3 u O |d|;
-//   * o x d: two roundings per component, 3.5 u O |d| in norm; m: 2 |o x d| times that plus three roundings: 10.1 O^2;
-//   * q: per component 4 u a |o_i| (a and its product) + 3 u O |d| |d_i| + u a O (the multiply-add), doubled: 17.6 u a O
-//     in norm, and |q| <= 2 a O;
-//   * w: three roundings and the centre's own rounding, 4 u C |d|; w^2: 8 C^2;
-//   * c.q: 17.6 C O + 2 C O (the centre's rounding);  a ks: 4 (C^2 + r^2) (a, the product, the rounding of ks);
-//   * five multiply-adds whose partial sums stay below 2 a S^2: 10 S^2.
-// Sum: 12 C^2 + 4 r^2 + 19.6 C O + 10.1 O^2 + 10 S^2 <= 22 S^2, a third of the band.  The same band bounds sqrt(disc)
-// from above in the body, and b = o.d - w is off by at most u |d| (3 O + 4 C + O + C) <= 5 u |d| S.  A ray that is the
-// rounding of a double-precision one (camera rays, origins with a residue) moves the discriminant by another
-// 6 u a S^2 and b by 2 u |d| S: 28 of the band's 72, and SphRay::eb = 8 u |d| S.
+// The discriminant b^2 - a cq (b = (o - c).d, cq = |o - c|^2 - r^2), divided by a, is evaluated in its expanded form
+// with the direction normalised once per ray, e = d rsqrt(a):
+//     disc / a = w^2 + c.q - m - ks,   w = c.e,   q = 2 (o - (o.e) e),   m = |o x e|^2 = |o|^2 - (o.e)^2,
+// ks = |c|^2 - r^2 from the row, e, q and m once per ray (SphRay).  The row then costs eight vector instructions -
+// three for w, four multiply-adds that start from band - m, and the compare of their sum with ks - where the
+// differences o - c cost twelve.  What it costs is cancellation at the scale of the scene instead of the scale of
+// |o - c|, and the band the test works with (72 u S^2, S = |o| + scene radius, as Ray::band0 / a) already is of that
+// scale.  Error against the exact discriminant / a of the float32 ray and the double-precision sphere, in units of u
+// (u = 2^-24; O = |o|, C = |c|, r the radius, C + r <= scene radius):
+//   * e: a carries 3 u, rsqrt 2 u (one ulp), the product u: |e| = 1 within 4 u, and e is off the direction of d by u per
+//     component - a ray like the rounding of a double-precision one, which moves the discriminant by 6 S^2;
+//     taking |e|^2 for 1 in "a o" and "a ks" costs 8 (2 C O + C^2 + r^2) <= 8 S^2;
+//   * o.e: 3 O; o x e: two roundings per component, 3.5 O in norm; m: 2 |o x e| times that plus three roundings: 10.1 O^2;
+//   * q: per component 3 O |e_i| + O (the multiply-add), doubled: 9.5 O in norm, and |q| <= 2 O;
+//   * w: three roundings and the centre's own rounding, 4 C; w^2: 8 C^2;
+//   * c.q: 9.5 C O + 2 C O (the centre's rounding); ks: its rounding, C^2 + r^2;
+//   * band - m and four multiply-adds whose partial sums stay below 2 S^2: 10 S^2.
+// Sum: 9 C^2 + r^2 + 11.5 C O + 10.1 O^2 + (6 + 8 + 10) S^2 <= 36 S^2, half the band.  A ray that is itself the rounding
+// of a double-precision one (camera rays, origins with a residue) adds 6 S^2.  The same band bounds sqrt(disc / a)
+// from above in the body, and b / |d| = o.e - w is off by at most u (3 O + 4 C + O + C + 2 S) <= 7 u S: SphRay::eb = 9 u S.
 //
 // The test runs for the whole wave or not at all: the branch is taken on a ballot (a scalar branch on the compare's own
 // mask; a divergent `if` costs a save, a branch and a restore of the execution mask per row), and the body has no
 // branches of its own - both cases of "is this the sphere the ray starts on" are worked out and selected.  Lanes whose
 // discriminant is below the band hand the sink +inf.
-struct SphRay { float qx, qy, qz, m, od, eb; };
+struct SphRay { float ex, ey, ez, qx, qy, qz, acc0, oe, eb, inv_len; };
 
 RT_DEV SphRay sph_ray(SceneRef S, const Ray &r) {
     SphRay q;
-    q.od = fma_(r.oz, r.dz, fma_(r.oy, r.dy, r.ox * r.dx));
-    const float kx = fma_(r.oy, r.dz, -(r.oz * r.dy)), ky = fma_(r.oz, r.dx, -(r.ox * r.dz)), kz = fma_(r.ox, r.dy, -(r.oy * r.dx));
-    q.m = fma_(kz, kz, fma_(ky, ky, kx * kx));
-    q.qx = 2.0f * fma_(-q.od, r.dx, r.a * r.ox); q.qy = 2.0f * fma_(-q.od, r.dy, r.a * r.oy); q.qz = 2.0f * fma_(-q.od, r.dz, r.a * r.oz);
-    q.eb = 8.0f * kU * r.dlen * (r.o2 + S.scene_radius);
+    q.inv_len = rsq_(r.a);
+    q.ex = r.dx * q.inv_len; q.ey = r.dy * q.inv_len; q.ez = r.dz * q.inv_len;
+    q.oe = fma_(r.oz, q.ez, fma_(r.oy, q.ey, r.ox * q.ex));
+    const float kx = fma_(r.oy, q.ez, -(r.oz * q.ey)), ky = fma_(r.oz, q.ex, -(r.ox * q.ez)), kz = fma_(r.ox, q.ey, -(r.oy * q.ex));
+    const float m = fma_(kz, kz, fma_(ky, ky, kx * kx));
+    q.qx = 2.0f * fma_(-q.oe, q.ex, r.ox); q.qy = 2.0f * fma_(-q.oe, q.ey, r.oy); q.qz = 2.0f * fma_(-q.oe, q.ez, r.oz);
+    const float Sr = r.o2 + S.scene_radius;
+    q.acc0 = fma_(72.0f * kU * Sr, Sr, -m);   // band - m
+    q.eb = 9.0f * kU * Sr;
     return q;
 }
 
 template <class Sink>
 RT_DEV void sphere_row_test(const SphLoopRow &P, const SphRay &q, const Ray &r, Sink &sink) {
-    const float w = fma_(P.cz, r.dz, fma_(P.cy, r.dy, P.cx * r.dx));
-    const float disc = fma_(w, w, fma_(P.cz, q.qz, fma_(P.cy, q.qy, fma_(P.cx, q.qx, fma_(-r.a, P.ks, -q.m)))));
-    const bool near = disc >= -r.band0;
+    const float w = fma_(P.cz, q.ez, fma_(P.cy, q.ey, P.cx * q.ex));
+    const float lhs = fma_(w, w, fma_(P.cz, q.qz, fma_(P.cy, q.qy, fma_(P.cx, q.qx, q.acc0))));   // disc / a + band + ks
+    const bool near = lhs >= P.ks;
     if (__ballot(near) != 0) {
-        const float sh = sqrt_(max_(disc + r.band0, 0.0f)) * (1.0f + 4.0f * kU);
-        const float nb = w - q.od;                   // -b
-        const float t1lo = (nb - sh - q.eb) * r.inv_a, t2lo = (nb - q.eb) * r.inv_a;
+        const float sh = sqrt_(max_(lhs - P.ks, 0.0f)) * (1.0f + 4.0f * kU);
+        const float nb = w - q.oe;                   // -b / |d|
+        const float t1lo = (nb - sh - q.eb) * q.inv_len, t2lo = (nb - q.eb) * q.inv_len;
         // the sphere the ray starts on: only the far root, only when heading inwards (b < eb); any other: a root ahead
         const bool own = P.gprim == r.origin;
         const float gate = own ? q.eb + nb : nb + sh + q.eb;
