@@ -96,7 +96,7 @@ struct rt_ctx {
     bool has_scene = false;
     DevScene S{};
     int tri_mode = 0; bool has_sph = false;
-    DevBuf tri_rows, quad_rows, slab_rows, box_rows, box_face_id, box_face_rows, leaf_rows, sph_rows, sph_loop, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
+    DevBuf tri_rows, quad_rows, slab_rows, box_rows, box_face_id, box_face_rows, leaf_rows, sph_rows, sph_loop, sph_loop_id, big_sph, tri_by_id, tri_aux, sph_by_id, sph_obj, materials;
     DevBuf tri_tight;
     DevBuf tri64, sph64, aabb64, mesh_tri_begin, obj_kind, obj_index, sky, bvh, bvh_wide, bvh_tri, cold;
     int32_t walk_stack_need = 0;   // stack entries the deepest walk of the current wide hierarchy can ask for
@@ -857,23 +857,24 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     HIP_TRY(c, c->tri_rows.upload(rows_live)); HIP_TRY(c, c->quad_rows.upload(rows_quad)); HIP_TRY(c, c->slab_rows.upload(rows_slab)); HIP_TRY(c, c->leaf_rows.upload(rows_leaf)); HIP_TRY(c, c->tri_by_id.upload(rows_all)); HIP_TRY(c, c->tri_aux.upload(aux));
     HIP_TRY(c, c->tri_tight.upload(tri_tight));
     const int n_sph_live = (int)sph_small.size();
-    // the search loop's own table: four rows per trip and two rows read ahead, so dead rows (never candidates) fill it
-    // up to a multiple of four and two more follow
+    // the search loop's own table: eight rows per trip and four rows read ahead, so dead rows (never candidates) fill it
+    // up to a multiple of eight and four more follow
     std::vector<SphLoopRow> sph_loop(n_sph_live);
+    std::vector<int32_t> sph_loop_id(n_sph_live);
     for (int i = 0; i < n_sph_live; ++i) {
         const SphRow &q = sph_small[i];
         const double *p = d->spheres + 4 * (size_t)q.gprim;
         SphLoopRow L{};
-        L.cx = q.cx; L.cy = q.cy; L.cz = q.cz; L.gprim = q.gprim;
+        L.cx = q.cx; L.cy = q.cy; L.cz = q.cz;
         L.ks = (float)(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] - p[3] * p[3]);
-        sph_loop[i] = L;
+        sph_loop[i] = L; sph_loop_id[i] = q.gprim;
     }
-    if (n_sph_live > 1) {
-        SphLoopRow dead{}; dead.ks = INFINITY; dead.gprim = -2;
-        while (sph_loop.size() % 4) sph_loop.push_back(dead);
-        sph_loop.push_back(dead); sph_loop.push_back(dead);
+    {
+        SphLoopRow dead{}; dead.ks = INFINITY;
+        while (sph_loop.size() % 8) { sph_loop.push_back(dead); sph_loop_id.push_back(-2); }
+        for (int k = 0; k < 4; ++k) { sph_loop.push_back(dead); sph_loop_id.push_back(-2); }
     }
-    HIP_TRY(c, c->sph_loop.upload(sph_loop));
+    HIP_TRY(c, c->sph_loop.upload(sph_loop)); HIP_TRY(c, c->sph_loop_id.upload(sph_loop_id));
     HIP_TRY(c, c->sph_rows.upload(sph_small)); HIP_TRY(c, c->sph_by_id.upload(sph_all)); HIP_TRY(c, c->big_sph.upload(big));
     HIP_TRY(c, c->sph_obj.upload(sobj)); HIP_TRY(c, c->materials.upload(mats));
     HIP_TRY(c, c->tri64.upload(tri64)); HIP_TRY(c, c->sph64.upload(sph64)); HIP_TRY(c, c->aabb64.upload(aabb64));
@@ -898,7 +899,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.slab_rows = c->slab_rows.as<SlabRow>(); S.n_quad_general = n_quad_general; S.slab_counts = slab_counts;
     S.box_rows = c->box_rows.as<BoxRow>(); S.box_face_id = c->box_face_id.as<int32_t>(); S.box_face_rows = c->box_face_rows.as<TriRow>();
     S.n_boxes = n_boxes; S.box_slack = up(1.01 * box_slack); S.box_tilt = up(1.01 * box_tilt + 1e-7);
-    S.sph_rows = c->sph_rows.as<SphRow>(); S.n_sph_rows = n_sph_live; S.sph_loop = c->sph_loop.as<SphLoopRow>();
+    S.sph_rows = c->sph_rows.as<SphRow>(); S.n_sph_rows = n_sph_live; S.sph_loop = c->sph_loop.as<SphLoopRow>(); S.sph_loop_id = c->sph_loop_id.as<int32_t>();
     S.big_sph = c->big_sph.as<int32_t>(); S.n_big_sph = (int)big.size();
     S.tri_by_id = c->tri_by_id.as<TriRow>(); S.tri_aux = c->tri_aux.as<TriAux>();
     S.sph_by_id = c->sph_by_id.as<SphRow>(); S.sph_obj = c->sph_obj.as<int32_t>();

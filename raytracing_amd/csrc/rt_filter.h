@@ -106,15 +106,18 @@ RT_DEV SphRow load_sph_row_uniform(const SphRow *rows, int i) {
     return P;
 }
 
-RT_DEV SphLoopRow load_sph_loop_row_uniform(const SphLoopRow *rows, int i) {
-    const_f4_ptr q = as_const_f4(rows) + 2 * (size_t)i;
-    f4 a = q[0], b = q[1];
-    SphLoopRow P;
-    P.cx = a.x; P.cy = a.y; P.cz = a.z; P.ks = a.w;
-    const float id_bits = b.x;
-    P.gprim = (int32_t)f2u(id_bits);
+struct SphLoopRow4 { SphLoopRow r[4]; };
+RT_DEV SphLoopRow4 load_sph_loop_rows_uniform(const SphLoopRow *rows, int i) {   // four rows: one s_load_dwordx16
+    const_f4_ptr q = as_const_f4(rows) + (size_t)i;
+    const f4 a = q[0], b = q[1], c = q[2], d = q[3];
+    SphLoopRow4 P;
+    P.r[0].cx = a.x; P.r[0].cy = a.y; P.r[0].cz = a.z; P.r[0].ks = a.w;
+    P.r[1].cx = b.x; P.r[1].cy = b.y; P.r[1].cz = b.z; P.r[1].ks = b.w;
+    P.r[2].cx = c.x; P.r[2].cy = c.y; P.r[2].cz = c.z; P.r[2].ks = c.w;
+    P.r[3].cx = d.x; P.r[3].cy = d.y; P.r[3].cz = d.z; P.r[3].ks = d.w;
     return P;
 }
+typedef const int32_t __attribute__((address_space(4))) *const_i32_ptr;
 
 RT_DEV SlabRow load_slab_row_uniform(const SlabRow *rows, int i) {
     const_f4_ptr q = as_const_f4(rows) + 3 * (size_t)i;
@@ -1094,7 +1097,7 @@ RT_DEV SphRay sph_ray(SceneRef S, const Ray &r) {
 }
 
 template <class Sink>
-RT_DEV void sphere_row_test(const SphLoopRow &P, const SphRay &q, const Ray &r, Sink &sink) {
+RT_DEV void sphere_row_test(const SphLoopRow &P, const int32_t *ids, int row, const SphRay &q, const Ray &r, Sink &sink) {
     const float w = fma_(P.cz, q.ez, fma_(P.cy, q.ey, P.cx * q.ex));
     const float lhs = fma_(w, w, fma_(P.cz, q.qz, fma_(P.cy, q.qy, fma_(P.cx, q.qx, q.acc0))));   // disc / a + band + ks
     const bool near = lhs >= P.ks;
@@ -1103,43 +1106,45 @@ RT_DEV void sphere_row_test(const SphLoopRow &P, const SphRay &q, const Ray &r, 
         const float nb = w - q.oe;                   // -b / |d|
         const float t1lo = (nb - sh - q.eb) * q.inv_len, t2lo = (nb - q.eb) * q.inv_len;
         // the sphere the ray starts on: only the far root, only when heading inwards (b < eb); any other: a root ahead
-        const bool own = P.gprim == r.origin;
+        const int32_t gprim = ((const_i32_ptr)ids)[row];   // (a scalar load, here where it is needed: one row in fifty)
+        const bool own = gprim == r.origin;
         const float gate = own ? q.eb + nb : nb + sh + q.eb;
         const bool valid = near & (gate > 0.0f);     // (bitwise: no short-circuit branch)
         float tl = own ? t2lo : t1lo;
         tl = max_(tl, 0.0f) * (1.0f - 8.0f * kU);
-        sink(valid ? tl : kInf, P.gprim);
+        sink(valid ? tl : kInf, gprim);
     }
 }
 
-// The small spheres, four per trip from four sets of scalar registers, two rows loaded at a time a pair of tests
-// ahead of their use; the row pointer moves once per trip and the loads take their offsets as immediates (one pointer
-// update and one loop test per four rows).  The host pads the table to a multiple of four with dead rows (ks = +inf:
-// the discriminant is -inf) plus two to read ahead into.
+// The small spheres, eight per trip: four rows come with one scalar load (sixteen dwords), issued four tests ahead of
+// their use into the register set the tests before last have left; the row pointer moves once per trip and the loads
+// take their offsets as immediates (one pointer update and one loop test per eight rows).  The host pads the table to a
+// multiple of eight with dead rows (ks = +inf: never "near") plus four to read ahead into.
 template <class Sink>
 RT_DEV void search_spheres(SceneRef S, const Ray &r, Sink &sink) {
     const int n_live = S.n_sph_rows;
     const SphLoopRow *p = S.sph_loop;
+    const int32_t *ids = S.sph_loop_id;
     if (n_live <= 0) return;
     const SphRay q = sph_ray(S, r);
-    if (n_live == 1) { sphere_row_test(load_sph_loop_row_uniform(p, 0), q, r, sink); return; }
-    int left = (n_live + 3) & ~3;
-    SphLoopRow A = load_sph_loop_row_uniform(p, 0), B = load_sph_loop_row_uniform(p, 1);
+    int row = 0;
+    const int n_pad = (n_live + 7) & ~7;
+    SphLoopRow4 A = load_sph_loop_rows_uniform(p, 0);
     do {
-        asm volatile("" : "+s"(p) : "s"(A.cx), "s"(B.cx));
-        const SphLoopRow C = load_sph_loop_row_uniform(p, 2), D = load_sph_loop_row_uniform(p, 3);
+        asm volatile("" : "+s"(p) : "s"(A.r[0].cx));
+        const SphLoopRow4 B = load_sph_loop_rows_uniform(p, 4);
         __builtin_amdgcn_sched_barrier(0);
-        sphere_row_test(A, q, r, sink);
-        sphere_row_test(B, q, r, sink);
+        sphere_row_test(A.r[0], ids, row + 0, q, r, sink); sphere_row_test(A.r[1], ids, row + 1, q, r, sink);
+        sphere_row_test(A.r[2], ids, row + 2, q, r, sink); sphere_row_test(A.r[3], ids, row + 3, q, r, sink);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+s"(p) : "s"(C.cx), "s"(D.cx));
-        A = load_sph_loop_row_uniform(p, 4); B = load_sph_loop_row_uniform(p, 5);
+        asm volatile("" : "+s"(p) : "s"(B.r[0].cx));
+        A = load_sph_loop_rows_uniform(p, 8);
         __builtin_amdgcn_sched_barrier(0);
-        sphere_row_test(C, q, r, sink);
-        sphere_row_test(D, q, r, sink);
-        p += 4;
-        left -= 4;
-    } while (left > 0);
+        sphere_row_test(B.r[0], ids, row + 4, q, r, sink); sphere_row_test(B.r[1], ids, row + 5, q, r, sink);
+        sphere_row_test(B.r[2], ids, row + 6, q, r, sink); sphere_row_test(B.r[3], ids, row + 7, q, r, sink);
+        p += 8;
+        row += 8;
+    } while (row < n_pad);
 }
 
 // The few huge spheres: double precision throughout.

@@ -87,11 +87,10 @@ struct SphRow {
 };
 
 // The same sphere as the search loop reads it (search_spheres): the discriminant in its expanded form needs the centre
-// and ks = |c|^2 - r^2 (from the double-precision centre and radius, rounded once).  8 dwords, dead rows: ks = +inf.
+// and ks = |c|^2 - r^2 (from the double-precision centre and radius, rounded once).  4 dwords (four rows come with one
+// s_load_dwordx16), dead rows: ks = +inf; the sphere's id is looked up only when a lane may hit it (DevScene::sph_loop_id).
 struct SphLoopRow {
     float cx, cy, cz, ks;
-    int32_t gprim;
-    float pad[3];
 };
 
 // Ray-origin tag (TriAux::tag, carried from a hit to the ray that leaves it):
@@ -201,6 +200,7 @@ struct DevScene {
     // per triangle (by triangle id), then per parallelogram row (by row index).  See judge_tri.
     const float *tri_tight;
     const SphLoopRow *sph_loop;                       // the small spheres again, in sph_rows' order, as the search loop reads them
+    const int32_t *sph_loop_id;                       // sphere index of every row of sph_loop
 };
 static_assert(offsetof(DevScene, tri_aux) == 64 && offsetof(DevScene, cam_pos) == 128, "DevScene: the two hot runs are 16 dwords each");
 
