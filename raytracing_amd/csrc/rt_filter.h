@@ -1148,15 +1148,11 @@ RT_DEV void search_spheres(SceneRef S, const Ray &r, Sink &sink) {
 }
 
 // The few huge spheres: double precision throughout.
+// `pre` (optional): receives the nearest one's verdict - its double-precision depth rounded once, which is all
+// hit_finish needs of it - so that a winner among them is not evaluated a second time.
+struct SpherePre;
 template <class Sink>
-RT_DEV void search_big_spheres(SceneRef S, const Ray &r, D3 o64, D3 d64, Sink &sink) {
-    for (int i = 0; i < S.n_big_sph; ++i) {
-        int si = S.big_sph[i];
-        ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
-        float tl = (float)eb.t * (1.0f - 4.0f * kU);
-        sink(eb.hit ? tl : kInf, si);
-    }
-}
+RT_DEV void search_big_spheres(SceneRef S, const Ray &r, D3 o64, D3 d64, Sink &sink, SpherePre *pre = nullptr);
 
 struct SphVerdict { int status; int root; float t, thi; };
 
@@ -1202,6 +1198,21 @@ RT_DEV SphVerdict judge_sphere(SceneRef S, int32_t si, const Ray &r, float rel_a
 // nearest sphere candidate is kept for hit_finish (SpherePre::id says whose it is).
 constexpr int kFewSpheres = 2;
 struct SpherePre { int32_t id; float tl; SphVerdict v; };
+
+template <class Sink>
+RT_DEV void search_big_spheres(SceneRef S, const Ray &r, D3 o64, D3 d64, Sink &sink, SpherePre *pre) {
+    for (int i = 0; i < S.n_big_sph; ++i) {
+        int si = S.big_sph[i];
+        ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
+        float tl = (float)eb.t * (1.0f - 4.0f * kU);
+        tl = eb.hit ? tl : kInf;
+        sink(tl, si);
+        if (pre != nullptr && tl < pre->tl) {
+            pre->tl = tl; pre->id = si;
+            pre->v.status = 0; pre->v.root = eb.prim; pre->v.t = (float)eb.t; pre->v.thi = pre->v.t * (1.0f + 2.0f * kU);
+        }
+    }
+}
 
 template <bool TIGHT, class Sink>
 RT_DEV void search_few_spheres(SceneRef S, const Ray &r, Sink &sink, SpherePre &pre, float rel_accept, float abs_accept) {
@@ -1327,7 +1338,8 @@ RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename Fi
         PROF(kProfSpheres);
         if (S.n_big_sph > 0) {
             const Ray64 x = ray64(S, r, rr);
-            search_big_spheres(S, r, x.o, x.d, first);
+            // (the verdict slot is the few-spheres path's when that runs; the huge spheres get it otherwise)
+            search_big_spheres(S, r, x.o, x.d, first, (pre != nullptr && S.n_sph_rows > kFewSpheres) ? pre : nullptr);
         }
         PROF(kProfBigSpheres);
     }
@@ -1376,9 +1388,13 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
                 // a huge sphere: its depth is exact already (double precision, as in the search loop);
                 // position and normal follow in float32 like any other hit's (|pos - c| / r is good
                 // to ~1e-7 however large r is)
-                const Ray64 x = ray64(S, r, rr);
-                const ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)gprim, x.o, x.d, gprim == r.origin, false);
-                status = eb.hit ? 0 : 2; t = (float)eb.t; thi = t * (1.0f + 2.0f * kU); root = eb.prim;
+                if (pre != nullptr && pre->id == gprim) {   // evaluated in the first pass already
+                    status = pre->v.status; t = pre->v.t; thi = pre->v.thi; root = pre->v.root;
+                } else {
+                    const Ray64 x = ray64(S, r, rr);
+                    const ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)gprim, x.o, x.d, gprim == r.origin, false);
+                    status = eb.hit ? 0 : 2; t = (float)eb.t; thi = t * (1.0f + 2.0f * kU); root = eb.prim;
+                }
             } else {
                 SphVerdict v;
                 if (pre != nullptr && pre->id == gprim) v = pre->v;   // worked out in the first pass already
