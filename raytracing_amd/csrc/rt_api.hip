@@ -918,6 +918,7 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         S.cam_pos[k] = (float)d->cam_pos[k];
         S.cam_res[k] = (float)(d->cam_pos[k] - (double)(float)d->cam_pos[k]);
     }
+    S.cam_rko = (S.cam_res[0] != 0.0f || S.cam_res[1] != 0.0f || S.cam_res[2] != 0.0f) ? 1.01f * kU : 0.0f;
     cold.cam64[12] = d->cam_d; cold.cam64[13] = d->cam_dof_strength; cold.cam64[14] = d->cam_dof_dist;
     HIP_TRY(c, c->cold.upload(std::vector<ColdScene>{cold}));
     S.cold = c->cold.as<ColdScene>();

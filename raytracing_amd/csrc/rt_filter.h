@@ -157,7 +157,6 @@ struct Ray {
     float a, inv_a, dlen;  // d.d, 1/(d.d), |d|
     float o2;              // |o| (rounded up)
     float c4, c7;          // triangle bounds: q = c7 |t| + c4 with c4 = 4u S, c7 = 7u |d|, S = |o| + scene_radius
-    float band0;           // crude per-ray discriminant bound for the in-loop sphere test
     float rk, rko;         // a camera ray is the float32 rounding of a double-precision ray: rk = 1.01 u bounds the relative
                            // rounding of its direction, rko = 1.01 u |o| the distance of its true origin (0 when the camera
                            // position is representable); both 0 for every other ray
@@ -190,9 +189,8 @@ RT_DEV Ray make_ray(SceneRef S, float ox, float oy, float oz, float dx, float dy
     const float k = (rounded || origin_rounded) ? 1.3f * kU : 1.01f * kU;
     r.c4 = 4.0f * k * Sr;
     r.c7 = 7.0f * k * r.dlen;
-    r.band0 = 72.0f * kU * r.a * Sr * Sr;
     r.rk = rounded ? 1.01f * kU : 0.0f;
-    r.rko = ((rounded && (S.cam_res[0] != 0.0f || S.cam_res[1] != 0.0f || S.cam_res[2] != 0.0f)) || origin_rounded) ? 1.01f * kU * r.o2 : 0.0f;
+    r.rko = (rounded ? S.cam_rko : (origin_rounded ? 1.01f * kU : 0.0f)) * r.o2;   // (a camera ray's origin has no residue of the other kind)
     r.origin = origin;
     r.own_idf = (float)(tag & kTagIdMask);
     r.own_sign = u2f(0x3F800000u | (tag & kTagSecond));
@@ -1061,7 +1059,7 @@ RT_DEV SphBounds sphere_bounds(const SphRow &P, const Ray &r) {
 // ks = |c|^2 - r^2 from the row, e, q and m once per ray (SphRay).  The row then costs eight vector instructions -
 // three for w, four multiply-adds that start from band - m, and the compare of their sum with ks - where the
 // differences o - c cost twelve.  What it costs is cancellation at the scale of the scene instead of the scale of
-// |o - c|, and the band the test works with (72 u S^2, S = |o| + scene radius, as Ray::band0 / a) already is of that
+// |o - c|, and the band the test works with (72 u S^2, S = |o| + scene radius) already is of that
 // scale.  Error against the exact discriminant / a of the float32 ray and the double-precision sphere, in units of u
 // (u = 2^-24; O = |o|, C = |c|, r the radius, C + r <= scene radius):
 //   * e: a carries 3 u, rsqrt 2 u (one ulp), the product u: |e| = 1 within 4 u, and e is off the direction of d by u per

@@ -181,7 +181,8 @@ struct DevScene {
     // ---- camera, environment
     // camera: float32 position and its double-precision residue (pinhole rays come from k_raygen's table)
     float cam_pos[3], cam_res[3];
-    const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale; int32_t pad0;   // environment: RGBA8 texels, row-major
+    const uint32_t *sky; int32_t sky_w, sky_h; float sky_scale;   // environment: RGBA8 texels, row-major
+    float cam_rko;            // 1.01 u when the camera position is not float32-representable (cam_res != 0), else 0: see Ray::rko
     // ---- boxes (see BoxRow)
     const BoxRow *box_rows;        // [n_boxes]
     const int32_t *box_face_id;    // [8 * n_boxes] by 8 * box + code: global id of the face's first triangle, -1 = no such face
