@@ -685,11 +685,15 @@ RT_DEV void box_loop(SceneRef S, const Ray &r, Sink &sink) {
 // instructions) before the row is used.
 template <class Sink>
 RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
-    if (S.n_quad_rows_padded > 0) {
+    // (the four counts sit side by side in the scene description and are read together, up front: one scalar load and
+    // one wait instead of one of each per table - the room has boxes only, and four empty tables cost its kernel 2 %)
+    const uint32_t slab_counts = S.slab_counts;
+    const int n_general = S.n_quad_general, n_quad_padded = S.n_quad_rows_padded, n_tri_padded = S.n_tri_rows_padded;
+    if (n_quad_padded > 0) {
         // one candidate per parallelogram: only the rows in general position; the rest follow in compact form
-        const int n = Sink::kPerTriangle ? S.n_quad_rows_padded : S.n_quad_general;
-        const TriRow *rows = S.quad_rows;
+        const int n = Sink::kPerTriangle ? n_quad_padded : n_general;
         if (n > 0) {
+            const TriRow *rows = S.quad_rows;
             TriRow cur = load_tri_row_uniform(rows, 0);
             for (int i = 0; i < n; ++i) {
                 const TriRow next = load_tri_row_uniform(rows, i + 1);
@@ -699,16 +703,16 @@ RT_DEV void search_tris(SceneRef S, const Ray &r, Sink &sink) {
         }
         if (!Sink::kPerTriangle) PROF(kProfQuadRows);
         if (!Sink::kPerTriangle) { box_loop(S, r, sink); PROF(kProfSlabRows); }
-        if (!Sink::kPerTriangle && S.slab_counts != 0) {
-            const int nx = (int)(S.slab_counts & 1023u), ny = (int)((S.slab_counts >> 10) & 1023u), nz = (int)(S.slab_counts >> 20);
+        if (!Sink::kPerTriangle && slab_counts != 0) {
+            const int nx = (int)(slab_counts & 1023u), ny = (int)((slab_counts >> 10) & 1023u), nz = (int)(slab_counts >> 20);
             slab_loop<0>(S.slab_rows, 0, nx, r, sink);
             slab_loop<1>(S.slab_rows, nx, ny, r, sink);
             slab_loop<2>(S.slab_rows, nx + ny, nz, r, sink);
             PROF(kProfSlabRows);
         }
     }
-    if (S.n_tri_rows_padded > 0) {
-        const int n = S.n_tri_rows_padded;   // rows [n, n+2) exist and are dead
+    if (n_tri_padded > 0) {
+        const int n = n_tri_padded;   // rows [n, n+2) exist and are dead
         const TriRow *rows = S.tri_rows;
         TriRow cur = load_tri_row_uniform(rows, 0);
         for (int i = 0; i < n; ++i) {
@@ -1332,6 +1336,14 @@ RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename Fi
     first.init(S);
     if (HAS_SPH) {
         if (pre != nullptr && S.n_sph_rows <= kFewSpheres) search_few_spheres<STRICT>(S, r, first, *pre, rel_accept, abs_accept);
+#if RT_DUP == 3
+        if (pre != nullptr && S.n_sph_rows <= kFewSpheres) {
+            typename FirstPass<TRI>::type dummy; dummy.init(S); SpherePre p2; p2.id = -1; p2.tl = kInf; p2.v.status = 2; p2.v.root = 0; p2.v.t = 0; p2.v.thi = 0;
+            Ray r2 = r; asm volatile("" : "+v"(r2.ox), "+v"(r2.dx));
+            search_few_spheres<STRICT>(S, r2, dummy, p2, rel_accept, abs_accept);
+            asm volatile("" :: "v"(dummy.best_id()), "v"(dummy.second_lo()), "v"(p2.v.t), "v"(p2.v.thi), "v"(p2.v.status), "v"(p2.id));
+        }
+#endif
         else search_spheres(S, r, first);
         PROF(kProfSpheres);
         if (S.n_big_sph > 0) {
@@ -1400,6 +1412,11 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
                 status = v.status; t = v.t; thi = v.thi; root = v.root;
             }
         } else {
+#if RT_DUP == 6
+            { int g2 = gprim - S.n_spheres; asm volatile("" : "+v"(g2));
+              const Verdict v2 = judge_tri<!FirstPass<TRI>::type::kPerTriangle, STRICT>(S, g2, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
+              asm volatile("" :: "v"(v2.status), "v"(v2.t), "v"(v2.thi), "v"(v2.ti), "v"(v2.ratio), "v"((int)v2.open)); }
+#endif
             const Verdict v = judge_tri<!FirstPass<TRI>::type::kPerTriangle, STRICT>(S, gprim - S.n_spheres, r,
                                                                              STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
             status = v.status; t = v.t; thi = v.thi; gprim = S.n_spheres + v.ti; pair_open = v.open; h.own_ratio = v.ratio;
