@@ -1336,14 +1336,6 @@ RT_DEV void hit_begin(SceneRef S, const Ray &r, const RayResidue rr, typename Fi
     first.init(S);
     if (HAS_SPH) {
         if (pre != nullptr && S.n_sph_rows <= kFewSpheres) search_few_spheres<STRICT>(S, r, first, *pre, rel_accept, abs_accept);
-#if RT_DUP == 3
-        if (pre != nullptr && S.n_sph_rows <= kFewSpheres) {
-            typename FirstPass<TRI>::type dummy; dummy.init(S); SpherePre p2; p2.id = -1; p2.tl = kInf; p2.v.status = 2; p2.v.root = 0; p2.v.t = 0; p2.v.thi = 0;
-            Ray r2 = r; asm volatile("" : "+v"(r2.ox), "+v"(r2.dx));
-            search_few_spheres<STRICT>(S, r2, dummy, p2, rel_accept, abs_accept);
-            asm volatile("" :: "v"(dummy.best_id()), "v"(dummy.second_lo()), "v"(p2.v.t), "v"(p2.v.thi), "v"(p2.v.status), "v"(p2.id));
-        }
-#endif
         else search_spheres(S, r, first);
         PROF(kProfSpheres);
         if (S.n_big_sph > 0) {
@@ -1412,11 +1404,6 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
                 status = v.status; t = v.t; thi = v.thi; root = v.root;
             }
         } else {
-#if RT_DUP == 6
-            { int g2 = gprim - S.n_spheres; asm volatile("" : "+v"(g2));
-              const Verdict v2 = judge_tri<!FirstPass<TRI>::type::kPerTriangle, STRICT>(S, g2, r, STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
-              asm volatile("" :: "v"(v2.status), "v"(v2.t), "v"(v2.thi), "v"(v2.ti), "v"(v2.ratio), "v"((int)v2.open)); }
-#endif
             const Verdict v = judge_tri<!FirstPass<TRI>::type::kPerTriangle, STRICT>(S, gprim - S.n_spheres, r,
                                                                              STRICT ? kRelAcceptStrict : kRelAcceptRender, abs_accept);
             status = v.status; t = v.t; thi = v.thi; gprim = S.n_spheres + v.ti; pair_open = v.open; h.own_ratio = v.ratio;

@@ -258,22 +258,12 @@ RT_DEV bool path_shade(SceneRef S, Path &p, int max_bounces, const Hit &h, float
     if (h.obj < 0) {
         sky_count += 1u;
         environment(S, p.dx, p.dy, p.dz, er, eg, eb);
-#if RT_DUP == 2
-        { float a, b, c, dx = p.dx; asm volatile("" : "+v"(dx)); environment(S, dx, p.dy, p.dz, a, b, c); asm volatile("" :: "v"(a), "v"(b), "v"(c)); }
-#endif
         return false;
     }
     PROF(kProfSky);
     const MatRow m = S.materials[h.obj];
     const Draws u = segment_draws(p.key0, p.key1, (uint32_t)p.depth + 1u);
     PROF(kProfDraws);
-#if RT_DUP == 1
-    { const Draws u2 = segment_draws(p.key0, p.key1, (uint32_t)p.depth + 17u); asm volatile("" :: "v"(u2.f0), "v"(u2.f1), "v"(u2.f2), "v"(u2.f3), "v"(u2.f4)); }
-#endif
-#if RT_DUP == 7
-    { MatRow m2 = m; Hit h2 = h; asm volatile("" : "+v"(h2.nx), "+v"(m2.r)); float dx = p.dx, dy = p.dy, dz = p.dz, tr = p.tr, tg = p.tg, tb = p.tb, e1 = 0, e2 = 0, e3 = 0; bool in2 = p.inside;
-      bool a2 = shade_bounce(m2, h2, u, dx, dy, dz, in2, tr, tg, tb, e1, e2, e3); asm volatile("" :: "v"(dx), "v"(dy), "v"(dz), "v"(tr), "v"(tg), "v"(tb), "v"(e1), "v"(e2), "v"(e3), "v"((int)a2), "v"((int)in2)); }
-#endif
     bool alive = shade_bounce(m, h, u, p.dx, p.dy, p.dz, p.inside, p.tr, p.tg, p.tb, er, eg, eb);
     p.ox = h.px; p.oy = h.py; p.oz = h.pz; p.origin = h.gprim; p.tag = h.tag; p.own_ratio = h.own_ratio;
     p.rox = h.rpx; p.roy = h.rpy; p.roz = h.rpz;
@@ -288,10 +278,6 @@ template <int TRI, bool HAS_SPH, bool STRICT = false, bool DEFER = false>
 RT_DEV bool path_step(SceneRef S, const float *ray_res, Path &p, int max_bounces, float &er, float &eg, float &eb, Hit &h,
                       uint32_t &sky_count) {
     Ray ray = make_ray(S, p.ox, p.oy, p.oz, p.dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio, path_origin_rounded(p));
-#if RT_DUP == 5
-    { float ox = p.ox, dx = p.dx; asm volatile("" : "+v"(ox), "+v"(dx)); Ray r2 = make_ray(S, ox, p.oy, p.oz, dx, p.dy, p.dz, p.origin, p.depth == 0, p.tag, p.own_ratio, path_origin_rounded(p));
-      asm volatile("" :: "v"(r2.a), "v"(r2.inv_a), "v"(r2.dlen), "v"(r2.o2), "v"(r2.c4), "v"(r2.c7), "v"(r2.rk), "v"(r2.rko), "v"(r2.own_idf), "v"(r2.own_sign), "v"(r2.own_box)); }
-#endif
     PROF(kProfRaySetup);
     h = closest_hit<TRI, HAS_SPH, STRICT, DEFER>(S, ray, nullptr, path_residue(S, ray_res, p));
     if (DEFER && h.how == kHowDeferred) { er = eg = eb = 0.0f; return false; }

@@ -12,9 +12,6 @@
 
 namespace rt {
 
-#ifndef RT_DUP
-#define RT_DUP 0   // cost experiments: a piece of the render path executed twice (results discarded)
-#endif
 constexpr float kU = 5.9604644775390625e-08f;  // 2^-24, unit roundoff of binary32
 
 // One live triangle, 16 dwords = one s_load_dwordx16.
