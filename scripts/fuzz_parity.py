@@ -3,7 +3,9 @@ hit identity, depth, normal and position of rt_intersect_batch against the oracl
 through a library-built hierarchy (free rays, bounce rays with their origin primitive, rays given as arbitrary
 doubles), then a small render of each scene against the oracle's.
 
-    python scripts/fuzz_parity.py [first_seed] [n_seeds] [seconds]
+    python scripts/fuzz_parity.py [first_seed] [n_seeds] [seconds] [big]
+
+`big`: fz.make_big_scene instead (12,000 clustered triangles, hierarchy only).
 
 Every disagreement is printed and the offending rays are written to gpurun_out/fuzz_seed<k>_<stage>.npz."""
 import dataclasses, os, sys, time
@@ -32,6 +34,7 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     budget = float(sys.argv[3]) if len(sys.argv) > 3 else 240.0
+    big = len(sys.argv) > 4 and sys.argv[4] == "big"
     os.makedirs(OUT, exist_ok=True)
     pool = fz.materials_pool()
     be = HipBackend(0)
@@ -41,7 +44,7 @@ def main():
         if time.time() - t0 > budget:
             break
         seeds += 1
-        sc, rng = fz.make_scene(seed, pool)
+        sc, rng = fz.make_big_scene(seed, pool) if big else fz.make_scene(seed, pool)
         o, d = fz.make_rays(sc, rng, 6000)
         want = h.oracle_intersect(sc, o, d)
         hit = want["obj"] >= 0
@@ -51,7 +54,7 @@ def main():
             want2 = h.oracle_intersect(sc, o2, d2, origin_prim=g2)
         od = rng.uniform(-1.6, 1.6, (4000, 3)); dd = rng.normal(size=(4000, 3)); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
         wantd = h.oracle_intersect(sc, od, dd)                 # doubles as they come: the exact code answers
-        for mode in ("linear", "hierarchy"):
+        for mode in (("hierarchy",) if big else ("linear", "hierarchy")):
             if mode == "linear":
                 with h.linear_tables():
                     be.set_scene(sc)
@@ -66,8 +69,8 @@ def main():
             px_all += 48 * 27; px_off += npx; paths_off += ndiff; paths_wrong += nwrong; paths_shading += nshade; paths_sky += nsky
             if nwrong or nshade:
                 print(f"  !! seed {seed} {mode} render: {nwrong} paths whose own ray the oracle answers differently, {nshade} with equal hits and another radiance", flush=True)
-        rays += 2 * (len(o) + len(o2) + len(od))
-        if seeds % 50 == 0:
+        rays += (1 if big else 2) * (len(o) + len(o2) + len(od))
+        if seeds % (10 if big else 50) == 0:
             print(f"{seeds} seeds, {rays} rays: {off} off, {ties} within sphere depth noise; pixels beyond 1e-3: {px_off} of {px_all} "
                   f"({paths_off} paths, {paths_wrong} wrong on their own ray, {paths_shading} shading, {paths_sky} sky texels); {time.time() - t0:.0f} s", flush=True)
     print(f"TOTAL seeds {first}..{first + seeds - 1}: {rays} rays, {off} off, {ties} answers within upstream's own sphere depth noise (libm pow); "

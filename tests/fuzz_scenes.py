@@ -207,3 +207,45 @@ def check_render(be, sc, W=48, H=27, spp=2, bounces=5):
             if own["obj"][0] != tr["obj"][i, k] or own["prim"][0] != tr["prim"][i, k]:
                 wrong += 1
     return len(px), differ, wrong, shading, sky
+
+
+def make_big_scene(seed, mats_pool, n_tris=12000):
+    """Thousands of small triangles in clusters (a hierarchy several levels deep, leaves that share edges and vertices
+    when the coordinates are snapped), a few strips of parallelograms, spheres among them, one huge sphere below."""
+    rng = np.random.default_rng(1_000_003 * seed + 17)
+    base = h.packed_scene("room")
+    snap = [None, 1.0 / 64, 1.0 / 32][seed % 3]
+    q = (lambda v: v) if snap is None else (lambda v: np.round(np.asarray(v) / snap) * snap)
+    n_clusters = int(rng.integers(6, 40))
+    centres = rng.uniform(-1.2, 1.2, (n_clusters, 3))
+    radii = rng.uniform(0.05, 0.5, n_clusters)
+    which = rng.integers(n_clusters, size=n_tris)
+    c = centres[which] + rng.normal(size=(n_tris, 3)) * radii[which, None]
+    size = rng.choice([0.01, 0.03, 0.1], size=(n_tris, 1, 1))
+    tris = q(c[:, None, :] + rng.normal(size=(n_tris, 3, 3)) * size).reshape(n_tris, 9)
+    strips = []
+    for _ in range(int(rng.integers(2, 8))):            # strips of parallelograms that share edges
+        a = q(rng.uniform(-1, 1, 3)); e1 = q(rng.normal(scale=0.1, size=3)); e2 = q(rng.normal(scale=0.1, size=3))
+        if not np.any(e1) or not np.any(e2):
+            continue
+        for k in range(int(rng.integers(4, 40))):
+            p0 = a + k * e1
+            strips += [np.concatenate([p0, p0 + e1, p0 + e1 + e2]), np.concatenate([p0, p0 + e1 + e2, p0 + e2])]
+    meshes = [tris] + ([np.array(strips)] if strips else [])
+    tv = np.concatenate(meshes)
+    begin = np.concatenate([[0], np.cumsum([len(m) for m in meshes])]).astype(np.int32)
+    aabb = np.array([np.concatenate([m.reshape(-1, 3).min(0), m.reshape(-1, 3).max(0)]) for m in meshes])
+    n_mesh = len(meshes)
+    sph = [np.concatenate([q(rng.uniform(-1, 1, 3)), [float(rng.choice([0.05, 0.125, 0.25]))]]) for _ in range(int(rng.integers(0, 12)))]
+    sph.append(np.array([0.0, -1002.0, 0.0, 1000.0]))
+    sph = np.array(sph, np.float64).reshape(-1, 4)
+    n_sph = len(sph)
+    kinds = np.array([1] * n_mesh + [0] * n_sph, np.int32)
+    index = np.array(list(range(n_mesh)) + list(range(n_sph)), np.int32)
+    mats = mats_pool[rng.integers(len(mats_pool), size=n_mesh + n_sph)]
+    sc = dataclasses.replace(base, obj_kind=kinds, obj_index=index, materials=np.ascontiguousarray(mats),
+                             spheres=np.ascontiguousarray(sph), sphere_obj=np.arange(n_sph, dtype=np.int32) + n_mesh,
+                             mesh_aabb=np.ascontiguousarray(aabb), mesh_obj=np.arange(n_mesh, dtype=np.int32),
+                             mesh_tri_begin=begin, tri_verts=np.ascontiguousarray(tv), object_names=["x"] * (n_mesh + n_sph),
+                             library_bvh=True)
+    return sc, rng
