@@ -477,6 +477,9 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
             }
             PROF(kProfBegin);
             // ---- 3. one path segment ----------------------------------------------------------
+            // (the path's Philox key is worked out again every trip - two exclusive-ors - from the pixel and the sample
+            // index, which live across trips anyway: two vector registers less over the loop's back edge)
+            p.key0 = p.pixel ^ A.seed_lo; p.key1 = (uint32_t)s_cur ^ A.seed_hi;
             float er = 0.0f, eg = 0.0f, eb = 0.0f;
             Hit h;
             bool alive = true;
