@@ -1132,6 +1132,14 @@ RT_DEV void search_spheres(SceneRef S, const Ray &r, Sink &sink) {
     int row = 0;
     const int n_pad = (n_live + 7) & ~7;
     SphLoopRow4 A = load_sph_loop_rows_uniform(p, 0);
+    if (n_live <= 4) {
+        // up to four spheres (the room's one beside a mesh in a hierarchy): one load, the live rows only
+        sphere_row_test(A.r[0], ids, 0, q, r, sink);
+        if (n_live > 1) sphere_row_test(A.r[1], ids, 1, q, r, sink);
+        if (n_live > 2) sphere_row_test(A.r[2], ids, 2, q, r, sink);
+        if (n_live > 3) sphere_row_test(A.r[3], ids, 3, q, r, sink);
+        return;
+    }
     do {
         asm volatile("" : "+s"(p) : "s"(A.r[0].cx));
         const SphLoopRow4 B = load_sph_loop_rows_uniform(p, 4);
