@@ -174,8 +174,8 @@ def check_render(be, sc, W=48, H=27, spp=2, bounces=5):
     """A small render against the oracle's.  Images may differ where float32 shading (a ray 1e-7 off upstream's) decides
     between coincident surfaces; what must hold is that on every path that differs, the first segment that names another
     hit is answered as the oracle answers THE KERNEL'S OWN RAY.  Returns (pixels that differ, paths that differ, paths
-    whose own ray the oracle answers differently, paths with equal hits but another radiance, paths with equal hits
-    that end in the sky on another texel)."""
+    whose own ray the oracle answers differently - plus pixels that differ though all their paths agree -, paths with
+    equal hits but another radiance, paths with equal hits that end in the sky on another texel)."""
     be.resize(W, H); be.reset_stats()
     be.render(W, H, 0, spp, bounces, h.SEED_RENDER); be.synchronize()
     img = be.read().astype(np.float64)
@@ -188,12 +188,14 @@ def check_render(be, sc, W=48, H=27, spp=2, bounces=5):
     xys = np.array([(x, y, s) for x, y in px for s in range(spp)], np.int32)
     tr = be.trace_paths(xys, W, H, bounces, h.SEED_RENDER)
     differ = wrong = shading = sky = 0
+    explained = set()   # pixels with at least one path that differs: the image's difference there has a cause
     with h.origin_rule():
         for i, (x, y, s) in enumerate(xys):
             want, _, _, seg = h.oracle_trace_pixel(sc, W, H, int(x), int(y), int(s), bounces, with_segments=True)
             if np.allclose(tr["rgb"][i], want, rtol=2e-3, atol=2e-4):
                 continue
             differ += 1
+            explained.add((int(x), int(y)))
             ns = min(int(tr["n_seg"][i]), len(seg["obj"]))
             k = next((k for k in range(ns) if tr["obj"][i, k] != seg["obj"][k] or tr["prim"][i, k] != seg["prim"][k]), None)
             if k is None:
@@ -206,6 +208,9 @@ def check_render(be, sc, W=48, H=27, spp=2, bounces=5):
             own = h.oracle_intersect(sc, tr["org"][i, k:k + 1], tr["dir"][i, k:k + 1].astype(np.float64), origin_prim=origin)
             if own["obj"][0] != tr["obj"][i, k] or own["prim"][0] != tr["prim"][i, k]:
                 wrong += 1
+    # a pixel of the rendered image that differs although every one of its paths, traced one by one, agrees with the
+    # oracle's: the render kernel and the path-by-path entry would disagree with each other - counted with `wrong`
+    wrong += sum(1 for x, y in px if (int(x), int(y)) not in explained)
     return len(px), differ, wrong, shading, sky
 
 
