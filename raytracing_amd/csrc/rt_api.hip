@@ -490,7 +490,8 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         row.r2 = (float)(r * r); row.r = (float)r; row.cn = up(norm(ctr)); row.gprim = s;
         // how far the float32 centre lies from the true one (0 when it is representable); negative marks the huge
         // spheres in the by-id table (the search rows never hold them)
-        row.qs = is_big ? -1.0f : up(norm(sub(ctr, V3{(double)row.cx, (double)row.cy, (double)row.cz})));
+        // (a huge sphere's marker carries what hit_finish needs of it: -2^-49 (|c| + r), the scale of the root's own noise)
+        row.qs = is_big ? -up(std::max(1.8e-15 * (norm(ctr) + r), 1e-30)) : up(norm(sub(ctr, V3{(double)row.cx, (double)row.cy, (double)row.cz})));
         sph_all[s] = row;
         if (is_big) big.push_back(s);
         else { sph_small.push_back(row); scene_radius = std::max(scene_radius, norm(ctr) + r); }
@@ -818,6 +819,20 @@ int rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     // ---- upload --------------------------------------------------------------------------------
     std::vector<double> tri64(d->tri_verts, d->tri_verts + 9 * (size_t)d->n_tris);
     std::vector<double> sph64(d->spheres, d->spheres + 4 * (size_t)d->n_spheres);
+    {
+        // radius**2 the way upstream's interpreter computes it: pow() of this machine's C library, called through a
+        // pointer the compiler cannot see through (it would turn pow(r, 2.0) into r * r, which is not always the same double)
+        double (*volatile lib_pow)(double, double) = static_cast<double (*)(double, double)>(&std::pow);
+        for (int s = 0; s < d->n_spheres; ++s) {
+            const double r = d->spheres[4 * (size_t)s + 3];
+#ifdef RT_LIBM_TABLES_GENERATED
+            sph64.push_back(lib_pow(r, 2.0));
+#else
+            sph64.push_back(r * r);
+            (void)lib_pow;
+#endif
+        }
+    }
     std::vector<double> aabb64(d->mesh_aabb, d->mesh_aabb + 6 * (size_t)d->n_meshes);
     std::vector<int32_t> mtb(d->n_meshes + 1, 0);
     for (int m = 0; m <= d->n_meshes && d->n_meshes; ++m) mtb[m] = d->mesh_tri_begin[m];

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include "rt_scene.h"
 
+#include "rt_libm_pow.h"
+
 namespace rt {
 
 #define RT_DEV __device__ __forceinline__
@@ -36,17 +38,23 @@ struct ExactHit {
 
 // Sphere.intersect restricted to its first hit that survives Scene.intersect's depth filter.
 // want_geometry = false skips position and normal (callers that only rank by depth).
-RT_DEV ExactHit exact_sphere(const double *sp, D3 o, D3 d, bool is_origin, bool want_geometry = true) {
+// LIBM: radius**2, b**2 and (...)**0.5 as upstream's interpreter computes them, through the C library's pow()
+// (rt_libm_pow.h) - the settling code's form, whose answers are final.  The search loops' form (LIBM false) squares
+// with a product and takes the root with sqrt: within an ulp of the other, a quarter of its instructions, and what it
+// feeds are float32 bounds with margins a million times that.
+// `r2`: radius**2 as the host's C library gives it (ColdScene::sph64 holds it behind the spheres), for LIBM callers.
+template <bool LIBM = true>
+RT_DEV ExactHit exact_sphere(const double *sp, D3 o, D3 d, bool is_origin, bool want_geometry = true, const double *r2 = nullptr) {
     ExactHit h; h.hit = false; h.prim = 0; h.t = 0; h.n = d3(0, 0, 0); h.pos = h.n;
     D3 c = d3(sp[0], sp[1], sp[2]);
     double radius = sp[3];
     D3 ro = dsub(o, c);
     double a = ddot(d, d);
     double b = 2 * ddot(ro, d);
-    double cc = ddot(ro, ro) - radius * radius;
-    double rad = b * b - 4 * a * cc;
+    double cc = ddot(ro, ro) - (LIBM ? (r2 != nullptr ? *r2 : libm_square(radius)) : radius * radius);
+    double rad = (LIBM ? libm_square(b) : b * b) - 4 * a * cc;
     if (!(rad >= 0)) return h;
-    double sq = __builtin_sqrt(rad);
+    double sq = LIBM ? libm_root(rad) : __builtin_sqrt(rad);
     double t1 = (-b - sq) / (2 * a), t2 = (-b + sq) / (2 * a);
     double t; int root;
     if (!is_origin) {
@@ -144,7 +152,7 @@ struct ScanHit { int32_t gprim; double t; };   // gprim < 0: miss
 // One primitive by global id, with its mesh's bounding-box gate.
 RT_DEV ExactHit exact_single(SceneRef S, int32_t gprim, D3 o, D3 d, int32_t origin) {
     const ColdScene &C = *S.cold;
-    if (gprim < S.n_spheres) return exact_sphere(C.sph64 + 4 * (size_t)gprim, o, d, gprim == origin);
+    if (gprim < S.n_spheres) return exact_sphere(C.sph64 + 4 * (size_t)gprim, o, d, gprim == origin, true, C.sph64 + 4 * (size_t)S.n_spheres + gprim);
     int32_t ti = gprim - S.n_spheres;
     ExactHit miss; miss.hit = false; miss.prim = 0; miss.t = 0; miss.n = d3(0, 0, 0); miss.pos = miss.n;
     if (gprim == origin) return miss;
@@ -160,7 +168,7 @@ RT_DEV ExactDepth exact_single_depth(SceneRef S, int32_t gprim, D3 o, D3 d, int3
     const ColdScene &C = *S.cold;
     ExactDepth r; r.hit = false; r.t = 0;
     ExactHit h;
-    if (gprim < S.n_spheres) h = exact_sphere(C.sph64 + 4 * (size_t)gprim, o, d, gprim == origin, false);
+    if (gprim < S.n_spheres) h = exact_sphere(C.sph64 + 4 * (size_t)gprim, o, d, gprim == origin, false, C.sph64 + 4 * (size_t)S.n_spheres + gprim);
     else {
         const int32_t ti = gprim - S.n_spheres;
         if (gprim == origin) return r;
@@ -180,7 +188,7 @@ RT_DEV ScanHit exact_scan(SceneRef S, D3 o, D3 d, int32_t origin) {
     for (int oi = 0; oi < C.n_objects; ++oi) {
         int idx = C.obj_index[oi];
         if (C.obj_kind[oi] == 0) {
-            ExactHit h = exact_sphere(C.sph64 + 4 * (size_t)idx, o, d, idx == origin, false);
+            ExactHit h = exact_sphere(C.sph64 + 4 * (size_t)idx, o, d, idx == origin, false, C.sph64 + 4 * (size_t)S.n_spheres + idx);
             if (h.hit && h.t < best.t) { best.gprim = idx; best.t = h.t; }
         } else {
             if (!exact_aabb(C.aabb64 + 6 * (size_t)idx, o, d)) continue;

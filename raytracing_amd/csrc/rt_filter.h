@@ -1158,6 +1158,16 @@ RT_DEV void search_spheres(SceneRef S, const Ray &r, Sink &sink) {
 }
 
 // The few huge spheres: double precision throughout.
+// Is the search loops' root of a huge sphere good enough as the hit's depth?  It is within an ulp or two of
+// |o - c| + r of upstream's (pow() against a product in b**2 - 4ac: rt_libm_pow.h) - nothing, unless the root itself is
+// that small (a ray that starts on a triangle lying in the sphere's surface): then the settling code, which squares as
+// upstream does, answers (status 2).  `qs`: the sphere's SphRow::qs, -2^-49 (|c| + r) for a huge sphere.
+template <bool STRICT>
+RT_DEV int big_sphere_status(bool hit, float t, float qs, const Ray &r) {
+    const float noise = fma_(1.8e-15f, r.o2, -qs);   // 2^-49 (|o| + |c| + r)
+    return (hit && noise <= (STRICT ? kRelAcceptStrict : kRelAcceptRender) * t) ? 0 : 2;
+}
+
 // `pre` (optional): receives the nearest one's verdict - its double-precision depth rounded once, which is all
 // hit_finish needs of it - so that a winner among them is not evaluated a second time.
 struct SpherePre;
@@ -1213,13 +1223,14 @@ template <class Sink>
 RT_DEV void search_big_spheres(SceneRef S, const Ray &r, D3 o64, D3 d64, Sink &sink, SpherePre *pre) {
     for (int i = 0; i < S.n_big_sph; ++i) {
         int si = S.big_sph[i];
-        ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
+        ExactHit eb = exact_sphere<false>(S.cold->sph64 + 4 * (size_t)si, o64, d64, si == r.origin, false);
         float tl = (float)eb.t * (1.0f - 4.0f * kU);
         tl = eb.hit ? tl : kInf;
         sink(tl, si);
         if (pre != nullptr && tl < pre->tl) {
             pre->tl = tl; pre->id = si;
-            pre->v.status = 0; pre->v.root = eb.prim; pre->v.t = (float)eb.t; pre->v.thi = pre->v.t * (1.0f + 2.0f * kU);
+            pre->v.root = eb.prim; pre->v.t = (float)eb.t; pre->v.thi = pre->v.t * (1.0f + 2.0f * kU);
+            pre->v.status = 0;   // (hit_finish looks at how small the root is: big_sphere_status)
         }
     }
 }
@@ -1394,7 +1405,8 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
         if (box_open) {
             gprim = -1;
         } else if (gprim < S.n_spheres) {
-            if (HAS_SPH && S.n_big_sph > 0 && S.sph_by_id[gprim].qs < 0.0f) {
+            const float qs_word = (HAS_SPH && S.n_big_sph > 0) ? S.sph_by_id[gprim].qs : 0.0f;
+            if (qs_word < 0.0f) {
                 // a huge sphere: its depth is exact already (double precision, as in the search loop);
                 // position and normal follow in float32 like any other hit's (|pos - c| / r is good
                 // to ~1e-7 however large r is)
@@ -1402,9 +1414,10 @@ RT_DEV Hit hit_finish(SceneRef S, const Ray &r, const RayResidue rr, const typen
                     status = pre->v.status; t = pre->v.t; thi = pre->v.thi; root = pre->v.root;
                 } else {
                     const Ray64 x = ray64(S, r, rr);
-                    const ExactHit eb = exact_sphere(S.cold->sph64 + 4 * (size_t)gprim, x.o, x.d, gprim == r.origin, false);
+                    const ExactHit eb = exact_sphere<false>(S.cold->sph64 + 4 * (size_t)gprim, x.o, x.d, gprim == r.origin, false);
                     status = eb.hit ? 0 : 2; t = (float)eb.t; thi = t * (1.0f + 2.0f * kU); root = eb.prim;
                 }
+                if (status == 0) status = big_sphere_status<STRICT>(true, t, qs_word, r);
             } else {
                 SphVerdict v;
                 if (pre != nullptr && pre->id == gprim) v = pre->v;   // worked out in the first pass already

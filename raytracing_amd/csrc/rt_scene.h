@@ -142,7 +142,7 @@ constexpr int kWalkColumn = kWalkStack + kWalkPending;
 // scalars into vector-register lanes inside the hot loop).
 struct ColdScene {
     const double *tri64;      // [n_tris][9] vertices as the host holds them
-    const double *sph64;      // [n_spheres][4]
+    const double *sph64;      // [n_spheres][4], then [n_spheres] radius**2 as the host's C library computes it (exact_sphere)
     const double *aabb64;     // [n_meshes][6]
     const int32_t *mesh_tri_begin;  // [n_meshes+1]
     const int32_t *obj_kind, *obj_index;

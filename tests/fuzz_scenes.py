@@ -140,8 +140,11 @@ def sphere_depth_noise(sc, o):
     """Absolute uncertainty of UPSTREAM'S OWN sphere depths for rays from `o`: sphere.py:18-19 and util.py:29-32 square
     through `**`, which is libm's pow() - correct to 0.52 ulp but not correctly rounded, so one time in some dozens
     b**2 is an ulp off b*b - and b**2 - 4ac cancels: the root moves by a few ulps of |o - c| + r (1.5e-11 for the
-    reference's own ground sphere of radius 1e5).  The kernels' exact code squares with a multiplication, so its sphere
-    depths agree with upstream's to that noise and not bit for bit; 2^-48 (|o| + |c| + r), largest sphere of the scene."""
+    reference's own ground sphere of radius 1e5).  A library built WITHOUT the C library's pow tables
+    (raytracing_amd/backend/build.py says so when it cannot find or verify them) squares with a multiplication, so its
+    sphere depths agree with upstream's to that noise and not bit for bit; with the tables the exact code restates pow()
+    and no answer needs this allowance (the campaign counts the ones that do: zero).  2^-48 (|o| + |c| + r), largest
+    sphere of the scene."""
     if len(sc.spheres) == 0:
         return np.zeros(len(o))
     reach = float((np.linalg.norm(sc.spheres[:, :3], axis=1) + sc.spheres[:, 3]).max())

@@ -464,3 +464,23 @@ def test_app_loop_ends_when_the_render_thread_dies(monkeypatch):
         else:
             res, _ = done["ret"]
             assert not res.finished and not res.failed and res.error is None
+
+
+def test_pow_restatement_equals_this_machines_pow():
+    """The build reads the tables of pow() out of the machine's libm, compiles the restatement the exact code uses
+    (csrc/rt_libm_pow.h) for the host and holds it against pow() on four million results; on this image (glibc 2.35)
+    that must succeed.  Elsewhere the build falls back to x*x and sqrt and says so - then there is nothing to test."""
+    from raytracing_amd.backend import build
+
+    had = os.path.exists(build.GEN_HEADER)
+    keep = open(build.GEN_HEADER).read() if had else None
+    try:
+        ok = build.generate_libm_tables(verbose=False)
+        if not ok:
+            pytest.skip("no verifiable pow tables on this machine")
+        text = open(build.GEN_HEADER).read()
+        assert "kLogTab[128][3]" in text and "kExpTab[256]" in text
+    finally:
+        if keep is not None:
+            with open(build.GEN_HEADER, "w") as f:
+                f.write(keep)
