@@ -86,8 +86,23 @@ double pow_core(double x, double y) {
 RT_LIBM_FN bool in_range(double ax) { return ax >= 0x1p-500 && ax <= 0x1p500; }   // (false for a NaN)
 }  // namespace libm
 
-RT_LIBM_FN double libm_square(double x) { const double ax = __builtin_fabs(x); return libm::in_range(ax) ? libm::pow_core(ax, 2.0) : x * x; }
-RT_LIBM_FN double libm_root(double x) { return libm::in_range(x) ? libm::pow_core(x, 0.5) : __builtin_sqrt(x); }
+// Nine times in ten the plain result is provably the library's: pow() is good to 0.52 ulp, so it can only name the
+// plain result's NEIGHBOUR when the exact value lies within 0.02 ulp of the half-way point between the two (on 200
+// million arguments each, pow(x, 2) != x * x and pow(x, 0.5) != sqrt(x) only within 0.009 ulp of it).  The exact
+// residual of the plain result says how far it is: below 0.45 ulp, the plain result stands and the tables stay unread.
+RT_LIBM_FN double libm_square(double x) {
+    const double p = x * x, e = __builtin_fma(x, x, -p);                                  // x^2 = p + e exactly
+    const double scale = libm::from_bits(libm::bits(p) & 0x7ff0000000000000ull);          // ulp(p) = scale 2^-52
+    if (__builtin_fabs(e) * 0x1p52 <= 0.45 * scale) return p;
+    const double ax = __builtin_fabs(x);
+    return libm::in_range(ax) ? libm::pow_core(ax, 2.0) : p;
+}
+RT_LIBM_FN double libm_root(double x) {
+    const double q = __builtin_sqrt(x), e = __builtin_fma(q, q, -x);                      // q^2 - x exactly; q - sqrt(x) = e / 2q to first order
+    const double scale = libm::from_bits(libm::bits(q) & 0x7ff0000000000000ull);
+    if (__builtin_fabs(e) * 0x1p52 <= 0.9 * q * scale) return q;
+    return libm::in_range(x) ? libm::pow_core(x, 0.5) : q;
+}
 #else
 RT_LIBM_FN double libm_square(double x) { return x * x; }
 RT_LIBM_FN double libm_root(double x) { return __builtin_sqrt(x); }
