@@ -361,6 +361,12 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
     // the hierarchy kernel's LDS is spoken for (4 KB more cost it a workgroup per CU: +11 %).
     constexpr bool kJobRayLds = TRI == kTriBrute;
     __shared__ f4 job_ray[kJobRayLds ? 256 : 1];
+    // ... and the entries of a whole job window are fetched when the wave takes the window, by all 64 lanes at once (one
+    // wait for memory per 64 jobs; fetched at the hand-out, every hand-out - a few lanes' worth of jobs - waited for
+    // its own cold lines while the whole wave stood by)
+    __shared__ f4 win_ray[kJobRayLds ? 256 : 1];
+    uint32_t win_base = 0;
+    bool win_staged = false;
     // hierarchy only: a closest-hit query in progress (walked a slice per trip of the main loop)
     typename FirstPass<TRI>::type first;
     first.init(S);
@@ -407,6 +413,21 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
                 if (base >= n_jobs) { drained = true; break; }
                 win_next = base;
                 win_end = base + window < n_jobs ? base + window : n_jobs;
+                if (kJobRayLds) {
+                    win_base = base;
+                    win_staged = JOB(job_list) == nullptr && !(!LEAN && JOB(path_mode));
+                    if (win_staged) {
+                        const uint32_t wj = base + lane_id();
+                        if (wj < win_end) {
+                            const FastDiv div_ch = {JOB(div_chunks.d), JOB(div_chunks.m), JOB(div_chunks.sh1), JOB(div_chunks.sh2)};
+                            const FastDiv div_h = {JOB(div_rect_h.d), JOB(div_rect_h.m), JOB(div_rect_h.sh1), JOB(div_rect_h.sh2)};
+                            const uint32_t wpl = fast_div(wj, div_ch), wcol = fast_div(wpl, div_h);
+                            const int wpx = JOB(x0) + (int)wcol, wpy = JOB(y0) + (int)(wpl - wcol * (uint32_t)JOB(rect_h));
+                            win_ray[threadIdx.x] = *(const f4 *)(A.ray_dir + 4 * (size_t)(uint32_t)(wpx * JOB(height) + wpy));
+                        }
+                        __builtin_amdgcn_wave_barrier();   // (other lanes of this wave read these entries below: LDS serves a wave's accesses in order)
+                    }
+                }
             }
             uint32_t avail = win_end - win_next;
             uint32_t r = rank_in(idle);
@@ -451,7 +472,10 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
                 ar = ag = ab = 0.0;
                 job_rays0 = l_rays; job_sky0 = l_sky; job_last_rec = -1;
                 have_job = true; in_path = false;
-                if (kJobRayLds) job_ray[threadIdx.x] = *(const f4 *)(A.ray_dir + 4 * (size_t)p.pixel);
+                if (kJobRayLds) {
+                    if (win_staged) job_ray[threadIdx.x] = win_ray[(threadIdx.x & ~63u) + ((slot - win_base) & 63u)];
+                    else job_ray[threadIdx.x] = *(const f4 *)(A.ray_dir + 4 * (size_t)p.pixel);
+                }
                 }
             }
             uint32_t want = (uint32_t)__builtin_popcountll(idle);
