@@ -1486,6 +1486,16 @@ int rt_debug_section_cycles(rt_ctx *c, unsigned long long *out, int n) {
 }
 #endif
 
+#ifdef RT_WAVE_END
+int rt_debug_wave_log(rt_ctx *c, unsigned long long *out, int n) {
+    if (!c || !out) return RT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_log), sizeof(unsigned long long) * (size_t)std::min(n, 6 * 8192)));
+    return RT_OK;
+}
+#endif
+
 int rt_reset_stats(rt_ctx *c) {
     if (!c) return RT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));

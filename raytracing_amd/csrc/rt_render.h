@@ -305,6 +305,9 @@ RT_DEV KernargRenderArgs kernarg_render_args() {
     return (KernargRenderArgs)((cbyte)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DevScene) + 7) & ~(size_t)7));
 }
 
+#ifdef RT_WAVE_END   // diagnostic builds: per wave of the lean kernel, when it started, ran dry and ended (100 MHz clock), trips and busy lanes after running dry
+__device__ unsigned long long g_wave_log[6 * 8192];
+#endif
 #ifndef RT_JOB_BLOCK
 #define RT_JOB_BLOCK 64
 #endif
@@ -378,6 +381,11 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
         g_prof_last[threadIdx.x >> 6] = (unsigned)__builtin_amdgcn_s_memtime();
     }
 #endif
+#ifdef RT_WAVE_END   // diagnostic builds: when the waves of a launch start, run dry and end (100 MHz clock), in the reason slots 8-13
+    const unsigned long long wave_t0 = wall_clock64();
+    unsigned long long wave_dry = 0;
+    unsigned trips_dry = 0, lanes_at_dry = 0;
+#endif
     KernargRenderArgs J = kernarg_render_args();
     ScenePtr Sp = kernarg_scene();
     // (spheres-only kernels measured 2 % faster with the plain by-value arguments)
@@ -410,7 +418,12 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
                 base = __builtin_amdgcn_readfirstlane(base);
                 uint32_t n_jobs = JOB(job_list_count) != nullptr ? *JOB(job_list_count) : JOB(total_jobs);
                 if (!LEAN && JOB(path_mode) && n_jobs > JOB(aside_cap)) n_jobs = JOB(aside_cap);
-                if (base >= n_jobs) { drained = true; break; }
+                if (base >= n_jobs) {
+#ifdef RT_WAVE_END
+                    if (!drained) { wave_dry = wall_clock64(); lanes_at_dry = (unsigned)__builtin_popcountll(__ballot(have_job)); }
+#endif
+                    drained = true; break;
+                }
                 win_next = base;
                 win_end = base + window < n_jobs ? base + window : n_jobs;
                 if (kJobRayLds) {
@@ -483,6 +496,9 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
             idle = __ballot(!have_job);
         }
         if (__ballot(have_job) == 0) break;
+#ifdef RT_WAVE_END
+        if (drained) ++trips_dry;
+#endif
         PROF(kProfHandout);
         PROF_LANES(kProfLanesJob, have_job);
 
@@ -632,6 +648,12 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
 #ifdef RT_SECTION_TIMERS
     if (lane_id() == 0 && A.prof != nullptr)
         for (int k = 0; k < kProfCount; ++k) atomicAdd(A.prof + k, (unsigned long long)g_prof_acc[threadIdx.x >> 6][k]);
+#endif
+#ifdef RT_WAVE_END
+    if (LEAN && lane_id() == 0) {
+        unsigned long long *w = g_wave_log + 6 * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+        w[0] = wave_t0; w[1] = wave_dry; w[2] = wall_clock64(); w[3] = trips_dry; w[4] = lanes_at_dry; w[5] = 1;
+    }
 #endif
     // ---- statistics: one atomic per counter per wave ------------------------------------------
     unsigned long long nodes = bc.nodes, tris = bc.tris, w_rays = l_rays, w_sky = l_sky;
