@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, (LEAN && TRI != RT_BVH_FOUR_WAVES) ? RT_LEAN_W
                 win_end = base + window < n_jobs ? base + window : n_jobs;
                 if (kJobRayLds) {
                     win_base = base;
-                    win_staged = JOB(job_list) == nullptr && !(!LEAN && JOB(path_mode));
+                    win_staged = kJobBlock <= 64 && JOB(job_list) == nullptr && !(!LEAN && JOB(path_mode));   // (a lane per job of the window)
                     if (win_staged) {
                         const uint32_t wj = base + lane_id();
                         if (wj < win_end) {
