@@ -24,7 +24,10 @@
 // both forms trace identical paths.  Same-address atomics cost ~8 ns each on this GPU: queue appends and statistics
 // are aggregated per wave or per block.
 //
-// Measured: see the design notes (wavefront against single-kernel pipeline on the 1.18 M-triangle scene).
+// Measured (room + 1.18 M triangles, 1920x1080, 32 spp, one MI355X): 73.6 ms with 64 M paths per batch, 103 ms with 16 M,
+// against 28.6 ms for the single persistent kernel - nine segments x three launches per batch each end with waves
+// waiting for their slowest lanes, the late segments' queues are too short to fill the chip, and every ray's state is
+// cold when its lane picks it up.  The single kernel is the default; this form is an option (RT_RENDER_WAVEFRONT).
 #pragma once
 #include <hip/hip_runtime.h>
 
