@@ -1244,9 +1244,11 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     // Job granularity: enough (pixel, chunk) jobs that every resident lane runs many of them, so the
     // end-of-launch tail (lanes waiting for the last jobs) stays a few percent of the launch.
     const long long lanes = (long long)c->n_cu * 2048;
-    // (measured with jobs numbered pixel by pixel, factors 24 / 48 / 96 / 192: room 45.96 / 45.61 / 46.86 / 48.46 ms per
-    // 256 spp, 1.18 M triangles 41.25 / 40.72 / 40.99 / 42.22 ms per 32 spp)
-    long long want_chunks = (48 * lanes + rect_px - 1) / rect_px;
+    // (measured, jobs numbered pixel by pixel, windows of 64 that halve near the end of the range, factors 16 / 24 / 32 /
+    // 48 / 64 / 80: room 46.40 / 46.16 / 46.18 / 46.47 / 46.73 / 47.2 ms per 256 spp and 23.70 / 23.81 / 23.99 / 24.28 per
+    // 128 spp - jobs of 25 to 40 samples; 1.18 M triangles, 128 spp: 105.1 / 104.8 / 104.8 / 104.8.  With windows of 256,
+    // factors 24 / 48 / 96 / 192 had measured 45.96 / 45.61 / 46.86 / 48.46 in the loose depth mode.)
+    long long want_chunks = (24 * lanes + rect_px - 1) / rect_px;
     // ... but no job shorter than eight samples: a call of few samples per pixel (one GPU's share of a frame that
     // many GPUs render together) would otherwise spend its time handing jobs out and folding their slots (measured,
     // 1080p room, 32 / 64 spp per call: 7.73 -> 7.15 ms and 13.58 -> 13.09 ms; at least 4 or 16 samples: 7.39 / 7.47 ms)
