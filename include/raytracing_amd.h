@@ -262,7 +262,7 @@ int rt_accum_read(rt_ctx *ctx, float *host_w_h_3);      /* blocking copy of the 
  * Scratch: a call needs, in context-owned device memory that only ever grows, 33 bytes per JOB (a job is a pixel
  * and a run of at least eight of its samples: at most rectangle x sample_count / 8 jobs, about 13 per pixel for
  * calls of 256 samples at 1080p) plus 96 bytes per set-aside path for up to 1/64 of the call's paths (at least
- * 4,096, at most 2^25 records), plus once per image size 48 bytes per pixel of camera rays: 1.8 GB for 1920 x 1080
+ * 4,096, at most 2^25 records), plus once per image size 48 bytes per pixel of camera rays: 1.4 GB for 1920 x 1080
  * x 256 samples in one call, 0.5 GB for the same image in calls of 32 samples.  Several contexts on one GPU each
  * hold their own; rt_release_scratch gives it back. */
 int rt_render(rt_ctx *ctx, const rt_render_params *params, float *accum_dev, void *stream);
