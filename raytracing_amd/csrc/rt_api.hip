@@ -1252,7 +1252,11 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     // ... but no job shorter than eight samples: a call of few samples per pixel (one GPU's share of a frame that
     // many GPUs render together) would otherwise spend its time handing jobs out and folding their slots (measured,
     // 1080p room, 32 / 64 spp per call: 7.73 -> 7.15 ms and 13.58 -> 13.09 ms; at least 4 or 16 samples: 7.39 / 7.47 ms)
-    want_chunks = std::min<long long>(want_chunks, std::max<long long>(1, p->sample_count / 8));
+    // Sixteen where a path segment is cheap (a few dozen table rows, no hierarchy): room, 32 / 64 spp per call 6.74 -> 6.62
+    // and 12.73 -> 12.45 ms (24 or 32: 7.05 / 12.6); where segments are dear, longer jobs only lengthen the launch's tail:
+    // spheres scene 32 spp 7.5 -> 7.9 ms, 1.18 M triangles 28.0 -> 29.4.
+    const bool cheap_segments = c->tri_mode != kTriBvh && c->S.n_tri_rows + c->S.n_sph_rows + c->S.n_big_sph <= 64;
+    want_chunks = std::min<long long>(want_chunks, std::max<long long>(1, p->sample_count / (cheap_segments ? 16 : 8)));
     int n_chunks = (int)std::min<long long>(std::max<long long>(want_chunks, 1), p->sample_count);
     int chunk_samples = (p->sample_count + n_chunks - 1) / n_chunks;
     n_chunks = (p->sample_count + chunk_samples - 1) / chunk_samples;
