@@ -1247,15 +1247,17 @@ int rt_render(rt_ctx *c, const rt_render_params *p, float *accum_dev, void *stre
     // (measured, jobs numbered pixel by pixel, windows of 64 that halve near the end of the range, factors 16 / 24 / 32 /
     // 48 / 64 / 80: room 46.40 / 46.16 / 46.18 / 46.47 / 46.73 / 47.2 ms per 256 spp and 23.70 / 23.81 / 23.99 / 24.28 per
     // 128 spp - jobs of 25 to 40 samples; 1.18 M triangles, 128 spp: 105.1 / 104.8 / 104.8 / 104.8.  With windows of 256,
-    // factors 24 / 48 / 96 / 192 had measured 45.96 / 45.61 / 46.86 / 48.46 in the loose depth mode.)
-    long long want_chunks = (24 * lanes + rect_px - 1) / rect_px;
+    // factors 24 / 48 / 96 / 192 had measured 45.96 / 45.61 / 46.86 / 48.46 in the loose depth mode.)  Where a path segment is
+    // dear - many table rows, or a hierarchy - longer jobs only lengthen the launch's tail: spheres scene, 64 spp, factor
+    // 24 / 48: 16.05 / 15.65 ms; there the factor stays 48.
+    const bool cheap_segments = c->tri_mode != kTriBvh && c->S.n_tri_rows + c->S.n_sph_rows + c->S.n_big_sph <= 64;   // a few dozen table rows, no hierarchy
+    long long want_chunks = ((cheap_segments ? 24 : 48) * lanes + rect_px - 1) / rect_px;
     // ... but no job shorter than eight samples: a call of few samples per pixel (one GPU's share of a frame that
     // many GPUs render together) would otherwise spend its time handing jobs out and folding their slots (measured,
     // 1080p room, 32 / 64 spp per call: 7.73 -> 7.15 ms and 13.58 -> 13.09 ms; at least 4 or 16 samples: 7.39 / 7.47 ms)
-    // Sixteen where a path segment is cheap (a few dozen table rows, no hierarchy): room, 32 / 64 spp per call 6.74 -> 6.62
+    // Sixteen where a path segment is cheap (see above): room, 32 / 64 spp per call 6.74 -> 6.62
     // and 12.73 -> 12.45 ms (24 or 32: 7.05 / 12.6); where segments are dear, longer jobs only lengthen the launch's tail:
     // spheres scene 32 spp 7.5 -> 7.9 ms, 1.18 M triangles 28.0 -> 29.4.
-    const bool cheap_segments = c->tri_mode != kTriBvh && c->S.n_tri_rows + c->S.n_sph_rows + c->S.n_big_sph <= 64;
     want_chunks = std::min<long long>(want_chunks, std::max<long long>(1, p->sample_count / (cheap_segments ? 16 : 8)));
     int n_chunks = (int)std::min<long long>(std::max<long long>(want_chunks, 1), p->sample_count);
     int chunk_samples = (p->sample_count + n_chunks - 1) / n_chunks;
